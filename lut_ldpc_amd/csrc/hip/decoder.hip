@@ -1,0 +1,632 @@
+// decoder.hip -- host logic and C-ABI of the MI355X LUT-LDPC decode path (include/lut_ldpc_hip.h).
+//
+// Replaces LDPC_Code_LUT::lut_decode and everything below it (src/LDPC_Code_LUT.cpp:259-469,
+// src/LUT_Tree.cpp:402-445,774-820) for a BATCH of frames: the frame loop of
+// LDPC_BER_Sim::sim_snr_point (src/LDPC_BER_Sim.cpp:260-291) becomes the innermost, coalesced
+// memory dimension.  See kernels_common.hpp for the HBM layout.
+#include "../../../include/lut_ldpc_hip.h"
+#include "kernels_common.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_fast.hpp"
+#include "lut_program.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace lutldpc;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(LUTLDPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size() ? h.size() : 1);
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct NodeClass {
+    int deg = 0;
+    std::vector<int> nodes;     // node ids, ascending
+    int tree_class = -1;        // index of the matching tree inside a tree set
+};
+
+struct PassPlan {               // one launch: all degree classes of one pass of one tree set
+    PassParams P{};
+    int lds_bytes = 0;
+    bool lds_tab = true;
+    bool valid = false;
+};
+
+}  // namespace
+
+struct lutldpc_decoder {
+    // ---- code
+    int nvar = 0, nchk = 0, E = 0;
+    std::vector<int> dv, dc, cn_msg_idx, vn_ptr, cn_ptr, cn_vn;
+    std::vector<NodeClass> vclass, cclass;
+    std::vector<int> vn_list, cn_list;         // nodes sorted by class
+    // ---- decoder parameters
+    int Nq_Cha = 0, max_iters_created = 0, max_iters = 0, psc = 1, pisc = 0, min_lut = 1;
+    std::vector<int> Nq_Msg, iter_set;         // iter_set = cumsum(reuse == 0) - 1
+    TreeArray var_trees, chk_trees;
+    // ---- programs: [set][class]
+    std::vector<std::vector<Program>> var_prog, chk_prog, dec_prog;
+    std::vector<Op> all_ops;
+    std::vector<uint8_t> all_tables;
+    std::vector<PassPlan> var_plan, chk_plan, dec_plan;   // per tree set
+    PassPlan cn_minsum_plan;
+    // ---- device
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevBuf<int32_t> d_vn_ptr, d_cn_ptr, d_cn_idx, d_cn_vn, d_vn_list, d_cn_list;
+    DevBuf<Op> d_ops;
+    DevBuf<uint8_t> d_tables;
+    // batch buffers
+    int Bcap = 0;
+    DevBuf<uint8_t> d_msgs, d_cha_t, d_msg0_t, d_hard, d_state, d_vfail;
+    DevBuf<int32_t> d_iters;
+    DevBuf<uint8_t> d_in_cha, d_in_msg, d_out_bits;   // frame-major staging for the host entry points
+    DevBuf<int32_t> d_out_iters;
+    DevBuf<double> d_llr, d_qb_cha, d_qb_msg;
+    DevBuf<int32_t> d_map;
+    // ---- tuning
+    int nodes_per_block = 16;
+    int use_fast = 1;
+    // ---- profiling
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> ev_live;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[LUTLDPC_K_COUNT] = {0};
+    int64_t prof_n[LUTLDPC_K_COUNT] = {0};
+    std::string describe;
+};
+
+namespace {
+
+// ----------------------------------------------------------------------------- profiling
+hipEvent_t ev_get(lutldpc_decoder *d) {
+    if (!d->ev_pool.empty()) { hipEvent_t e = d->ev_pool.back(); d->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_fold(lutldpc_decoder *d) {
+    if (d->ev_live.empty()) return;
+    (void)hipStreamSynchronize(d->stream);
+    for (auto &e : d->ev_live) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { d->prof_ms[e.kind] += ms; d->prof_n[e.kind]++; }
+        d->ev_pool.push_back(e.a); d->ev_pool.push_back(e.b);
+    }
+    d->ev_live.clear();
+}
+struct Timed {
+    lutldpc_decoder *d; int kind; hipEvent_t a{}, b{};
+    Timed(lutldpc_decoder *d_, int k) : d(d_), kind(k) {
+        if (d->profiling) { a = ev_get(d); b = ev_get(d); (void)hipEventRecord(a, d->stream); }
+    }
+    ~Timed() {
+        if (d->profiling) { (void)hipEventRecord(b, d->stream); d->ev_live.push_back({a, b, kind}); }
+    }
+};
+
+// ----------------------------------------------------------------------------- set-up helpers
+void build_classes(const std::vector<int> &deg, std::vector<NodeClass> &cls, std::vector<int> &list) {
+    std::map<int, std::vector<int>> by;
+    for (size_t i = 0; i < deg.size(); i++) by[deg[i]].push_back((int)i);
+    cls.clear(); list.clear();
+    for (auto &kv : by) { NodeClass c; c.deg = kv.first; c.nodes = kv.second; cls.push_back(std::move(c)); }
+    for (auto &c : cls) list.insert(list.end(), c.nodes.begin(), c.nodes.end());
+}
+
+// Build the launch plan of one pass from per-class programs (generic) -- progs may be empty
+// for the min-sum pass.
+int build_plan(lutldpc_decoder *d, const std::vector<NodeClass> &cls, const std::vector<Program> *progs,
+               const std::vector<size_t> *op_off, const std::vector<size_t> *tab_off, PassPlan &plan) {
+    if ((int)cls.size() > kMaxSeg) return fail(LUTLDPC_ERR_UNSUPPORTED, "more than 32 distinct node degrees in one pass");
+    PassParams &P = plan.P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_seg = (int)cls.size();
+    P.nodes_per_block = d->nodes_per_block;
+    P.E = d->E; P.N = d->nvar;
+    int blk = 0, node_off = 0, max_slots = 0, max_tab = 0;
+    for (size_t i = 0; i < cls.size(); i++) {
+        PassSeg &S = P.seg[i];
+        S.block_begin = blk;
+        S.n_nodes = (int)cls[i].nodes.size();
+        S.node_off = node_off;
+        S.deg = cls[i].deg;
+        if (progs) {
+            const Program &pr = (*progs)[i];
+            S.op_off = (int)(*op_off)[i]; S.n_ops = (int)pr.ops.size();
+            S.tab_off = (int)(*tab_off)[i]; S.tab_bytes = (int)pr.tables.size();
+            S.n_in = pr.n_in; S.n_out = pr.n_out; S.n_slots = pr.n_slots;
+            max_slots = std::max(max_slots, pr.n_slots);
+            max_tab = std::max(max_tab, (int)pr.tables.size());
+        }
+        blk += (S.n_nodes + P.nodes_per_block - 1) / P.nodes_per_block;
+        node_off += S.n_nodes;
+    }
+    P.blocks_per_group = blk;
+    P.slots_lds = max_slots;
+    int slots_bytes = max_slots * kWave * 4;
+    if (slots_bytes > 60 * 1024) return fail(LUTLDPC_ERR_UNSUPPORTED, "node program needs more than 60 KiB of LDS slots");
+    plan.lds_tab = (slots_bytes + max_tab) <= 64 * 1024;
+    plan.lds_bytes = slots_bytes + (plan.lds_tab ? max_tab : 0);
+    plan.valid = true;
+    return LUTLDPC_OK;
+}
+
+int compile_all(lutldpc_decoder *d) {
+    std::string err;
+    // match trees to degree classes like set_trees (src/LDPC_Code_LUT.cpp:133-139,152-158):
+    // VARTREE leaves == dv, CHKTREE leaves + 1 == dc, matched on tree set 0
+    if (d->var_trees.empty()) return fail(LUTLDPC_ERR_ARG, "no variable-node trees");
+    int n_sets = 0;
+    for (int i = 0; i < d->max_iters_created; i++) n_sets = std::max(n_sets, d->iter_set[(size_t)i] + 1);
+    if ((int)d->var_trees.size() < n_sets) return fail(LUTLDPC_ERR_ARG, "fewer variable tree sets than reuse_vec requires");
+    for (auto &c : d->vclass) {
+        c.tree_class = -1;
+        for (size_t k = 0; k < d->var_trees[0].size(); k++) if (d->var_trees[0][k].num_leaves == c.deg) { c.tree_class = (int)k; break; }
+        if (c.tree_class < 0) return fail(LUTLDPC_ERR_ARG, "no variable tree for degree " + std::to_string(c.deg));
+    }
+    if (!d->min_lut) {
+        if ((int)d->chk_trees.size() < n_sets) return fail(LUTLDPC_ERR_ARG, "fewer check tree sets than reuse_vec requires");
+        for (auto &c : d->cclass) {
+            c.tree_class = -1;
+            for (size_t k = 0; k < d->chk_trees[0].size(); k++) if (d->chk_trees[0][k].num_leaves + 1 == c.deg) { c.tree_class = (int)k; break; }
+            if (c.tree_class < 0) return fail(LUTLDPC_ERR_ARG, "no check tree for degree " + std::to_string(c.deg));
+        }
+    }
+    d->all_ops.clear(); d->all_tables.clear();
+    auto add_set = [&](const std::vector<Tree> &trees, const std::vector<NodeClass> &cls, int kind,
+                       std::vector<Program> &progs, PassPlan &plan) -> int {
+        progs.resize(cls.size());
+        std::vector<size_t> op_off(cls.size()), tab_off(cls.size());
+        for (size_t i = 0; i < cls.size(); i++) {
+            if (cls[i].tree_class >= (int)trees.size()) return fail(LUTLDPC_ERR_ARG, "tree set is missing a degree class");
+            const Tree &t = trees[(size_t)cls[i].tree_class];
+            std::string e;
+            if (!compile_program(t, kind, cls[i].deg, progs[i], e))
+                return fail(LUTLDPC_ERR_UNSUPPORTED, "degree " + std::to_string(cls[i].deg) + ": " + e);
+            op_off[i] = d->all_ops.size(); tab_off[i] = d->all_tables.size();
+            d->all_ops.insert(d->all_ops.end(), progs[i].ops.begin(), progs[i].ops.end());
+            d->all_tables.insert(d->all_tables.end(), progs[i].tables.begin(), progs[i].tables.end());
+        }
+        return build_plan(d, cls, &progs, &op_off, &tab_off, plan);
+    };
+    size_t ns = (size_t)n_sets;
+    d->var_prog.assign(ns, {}); d->dec_prog.assign(ns, {}); d->chk_prog.assign(ns, {});
+    d->var_plan.assign(ns, {}); d->dec_plan.assign(ns, {}); d->chk_plan.assign(ns, {});
+    for (size_t s = 0; s < ns; s++) {
+        // a set is either message-update trees or (the last one) decision trees
+        int type = d->var_trees[s].empty() ? TT_VAR : d->var_trees[s][0].type;
+        int rc;
+        if (type == TT_DEC) rc = add_set(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog[s], d->dec_plan[s]);
+        else rc = add_set(d->var_trees[s], d->vclass, TT_VAR, d->var_prog[s], d->var_plan[s]);
+        if (rc) return rc;
+        if (!d->min_lut) { rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s]); if (rc) return rc; }
+    }
+    if (d->min_lut) { int rc = build_plan(d, d->cclass, nullptr, nullptr, nullptr, d->cn_minsum_plan); if (rc) return rc; }
+    return LUTLDPC_OK;
+}
+
+int upload_static(lutldpc_decoder *d) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIP_TRY(d->d_vn_ptr.upload(d->vn_ptr));
+    HIP_TRY(d->d_cn_ptr.upload(d->cn_ptr));
+    HIP_TRY(d->d_cn_idx.upload(d->cn_msg_idx));
+    HIP_TRY(d->d_cn_vn.upload(d->cn_vn));
+    HIP_TRY(d->d_vn_list.upload(d->vn_list));
+    HIP_TRY(d->d_cn_list.upload(d->cn_list));
+    HIP_TRY(d->d_ops.upload(d->all_ops));
+    {   // pad the table blob so that dword staging never reads past the end
+        std::vector<uint8_t> t = d->all_tables;
+        t.resize((t.size() + 3) / 4 * 4 + 16, 0);
+        HIP_TRY(d->d_tables.upload(t));
+    }
+    return LUTLDPC_OK;
+}
+
+int ensure_batch(lutldpc_decoder *d, int B) {
+    int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames;
+    if (Bpad <= d->Bcap) return LUTLDPC_OK;
+    size_t G = (size_t)Bpad / kTileFrames;
+    HIP_TRY(d->d_msgs.alloc(G * (size_t)d->E * kTileFrames));
+    HIP_TRY(d->d_cha_t.alloc(G * (size_t)d->nvar * kTileFrames));
+    HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kTileFrames));
+    HIP_TRY(d->d_hard.alloc(G * (size_t)d->nvar * kTileFrames));
+    HIP_TRY(d->d_state.alloc((size_t)Bpad));
+    HIP_TRY(d->d_vfail.alloc((size_t)Bpad));
+    HIP_TRY(d->d_iters.alloc((size_t)Bpad));
+    d->Bcap = Bpad;
+    return LUTLDPC_OK;
+}
+
+#define LAUNCH_CHECK()                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) return fail(LUTLDPC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value) {
+    Timed t(d, LUTLDPC_K_LAYOUT);
+    hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(Bpad / 256)), dim3(256), 0, d->stream,
+                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, Bpad, mode, value);
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+int launch_syndrome(lutldpc_decoder *d, int G) {
+    Timed t(d, LUTLDPC_K_SYNDROME);
+    const int cpw = 8;
+    unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
+    hipLaunchKernelGGL(syndrome_bits_kernel, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+                       reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                       d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, d->nvar, cpw);
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+template <int KIND>
+int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, int G, int nz, int check, int write_hard, int kind_id) {
+    if (!plan.valid) return fail(LUTLDPC_ERR_STATE, "pass plan missing for this tree set");
+    Timed t(d, kind_id);
+    PassParams P = plan.P;
+    P.G = G; P.nz = nz; P.check = check; P.write_hard = write_hard;
+    // specialised kernels take the classes they know; the interpreter handles the rest
+    if (d->use_fast && KIND != TT_CHK) {
+        int rc = launch_fast_tree_pass<KIND>(d->stream, P, plan.lds_tab, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
+                                             reinterpret_cast<const uint32_t *>(d->d_state.p),
+                                             reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_ops.p, d->d_tables.p,
+                                             d->d_vn_list.p, d->d_vn_ptr.p);
+        if (rc < 0) return fail(LUTLDPC_ERR_HIP, "fast pass launch failed");
+        if (rc == 1) { LAUNCH_CHECK(); return LUTLDPC_OK; }
+    }
+    dim3 grid((unsigned)(P.blocks_per_group * G)), block(64);
+    const int32_t *list = KIND == TT_CHK ? d->d_cn_list.p : d->d_vn_list.p;
+    const int32_t *ptr = KIND == TT_CHK ? d->d_cn_ptr.p : d->d_vn_ptr.p;
+    if (plan.lds_tab)
+        hipLaunchKernelGGL((tree_pass_kernel<KIND, true>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+                           d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                           d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
+    else
+        hipLaunchKernelGGL((tree_pass_kernel<KIND, false>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+                           d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                           d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
+    Timed t(d, LUTLDPC_K_CN_PASS);
+    PassParams P = d->cn_minsum_plan.P;
+    P.G = G; P.nz = nz; P.check = check;
+    if (d->use_fast) {
+        int rc = launch_fast_cn_minsum(d->stream, P, d->d_msgs.p, reinterpret_cast<const uint32_t *>(d->d_state.p),
+                                       reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
+        if (rc < 0) return fail(LUTLDPC_ERR_HIP, "fast check pass launch failed");
+        if (rc == 1) { LAUNCH_CHECK(); return LUTLDPC_OK; }
+    }
+    hipLaunchKernelGGL(cn_minsum_generic_kernel, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
+                       reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                       d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+// The batched lut_decode (src/LDPC_Code_LUT.cpp:259-353) on device-resident frame-major labels.
+int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B, uint8_t *d_out_bits, int32_t *d_out_iters) {
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
+    HIP_TRY(hipSetDevice(d->device));
+    int rc = ensure_batch(d, B);
+    if (rc) return rc;
+    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames;
+    const int N = d->nvar, E = d->E, I = d->max_iters;
+    const int last_set = d->iter_set[(size_t)(I - 1)];
+    if (!d->dec_plan[(size_t)last_set].valid)
+        return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
+
+    if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
+    {
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
+        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha);
+        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]);
+        LAUNCH_CHECK();
+    }
+    if (d->pisc) {   // :275-279
+        {
+            Timed t(d, LUTLDPC_K_LAYOUT);
+            size_t nw = (size_t)G * N * kTileFrames / 4;
+            hipLaunchKernelGGL(hard_from_labels_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, nw, d->Nq_Cha / 2);
+            LAUNCH_CHECK();
+        }
+        if ((rc = launch_syndrome(d, G))) return rc;
+        if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
+    }
+    {   // :284-289
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
+        LAUNCH_CHECK();
+    }
+    for (int ii = 0; ii < I; ii++) {   // :301-338
+        const int set = d->iter_set[(size_t)ii];
+        const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
+        const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
+        if (d->min_lut) rc = launch_cn_minsum(d, G, nz_in, chk_check);
+        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
+        if (rc) return rc;
+        if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
+        if (ii != I - 1) {
+            const int nz_out = d->Nq_Msg[(size_t)(ii + 1)] / 2;
+            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
+            if (rc) return rc;
+        }
+    }
+    // :340-349
+    if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
+    if ((rc = launch_syndrome(d, G))) return rc;
+    if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
+    {
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p, d_out_bits, B, N);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(d_out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToDevice, d->stream));
+    }
+    if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
+    return LUTLDPC_OK;
+}
+
+void make_describe(lutldpc_decoder *d) {
+    std::ostringstream o;
+    o << "{\"tile_frames\":" << kTileFrames << ",\"message_bytes\":1,\"vector_bytes_per_lane\":4"
+      << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"use_fast\":" << d->use_fast
+      << ",\"vn_classes\":[";
+    for (size_t i = 0; i < d->vclass.size(); i++) o << (i ? "," : "") << "{\"deg\":" << d->vclass[i].deg << ",\"nodes\":" << d->vclass[i].nodes.size()
+        << ",\"kernel\":\"" << fast_vn_kernel_name(d->use_fast, d->vclass[i].deg, d->var_prog.empty() || d->var_prog[0].empty() ? nullptr : &d->var_prog[0][i]) << "\"}";
+    o << "],\"cn_classes\":[";
+    for (size_t i = 0; i < d->cclass.size(); i++) o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size()
+        << ",\"kernel\":\"" << (d->min_lut ? fast_cn_kernel_name(d->use_fast, d->cclass[i].deg) : "tree_pass_kernel<CHK>") << "\"}";
+    o << "]}";
+    d->describe = o.str();
+}
+
+}  // namespace
+
+// =============================================================================== C-ABI
+extern "C" {
+
+const char *lutldpc_last_error(void) { return g_err.c_str(); }
+const char *lutldpc_version(void) { return "lut_ldpc_amd 0.1 gfx950"; }
+
+int lutldpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t *dc, const int32_t *cn_msg_idx,
+                           int Nq_Cha, const int32_t *Nq_Msg, const uint8_t *reuse_vec, int max_iters,
+                           int min_lut, const char *var_trees_txt, const char *chk_trees_txt, int device,
+                           lutldpc_decoder **out) {
+    if (!out) return fail(LUTLDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nvar <= 0 || nchk <= 0 || !dv || !dc || !cn_msg_idx || !Nq_Msg || !reuse_vec || max_iters < 1 || !var_trees_txt)
+        return fail(LUTLDPC_ERR_ARG, "missing or non-positive argument");
+    if (Nq_Cha < 2 || Nq_Cha > 128 || (Nq_Cha & 1)) return fail(LUTLDPC_ERR_ARG, "Nq_Cha must be even and in [2,128]");
+    for (int i = 0; i < max_iters; i++)
+        if (Nq_Msg[i] < 2 || Nq_Msg[i] > 128 || (Nq_Msg[i] & 1)) return fail(LUTLDPC_ERR_ARG, "Nq_Msg entries must be even and in [2,128]");
+    // src/LDPC_Code_LUT.cpp:122
+    if (reuse_vec[0] || reuse_vec[max_iters - 1]) return fail(LUTLDPC_ERR_ARG, "first and last iteration are exempt from tree reuse");
+    std::unique_ptr<lutldpc_decoder> d(new lutldpc_decoder);
+    d->nvar = nvar; d->nchk = nchk;
+    d->dv.assign(dv, dv + nvar); d->dc.assign(dc, dc + nchk);
+    long long ev = 0, ec = 0;
+    for (int v = 0; v < nvar; v++) { if (dv[v] < 1 || dv[v] > 255) return fail(LUTLDPC_ERR_ARG, "variable degree outside [1,255]"); ev += dv[v]; }
+    for (int c = 0; c < nchk; c++) { if (dc[c] < 1 || dc[c] > 255) return fail(LUTLDPC_ERR_ARG, "check degree outside [1,255]"); ec += dc[c]; }
+    if (ev != ec || ev > (1ll << 30)) return fail(LUTLDPC_ERR_ARG, "sum(dv) != sum(dc)");
+    d->E = (int)ev;
+    d->cn_msg_idx.assign(cn_msg_idx, cn_msg_idx + d->E);
+    d->vn_ptr.resize((size_t)nvar + 1); d->cn_ptr.resize((size_t)nchk + 1);
+    for (int v = 0; v < nvar; v++) d->vn_ptr[(size_t)v + 1] = d->vn_ptr[(size_t)v] + dv[v];
+    for (int c = 0; c < nchk; c++) d->cn_ptr[(size_t)c + 1] = d->cn_ptr[(size_t)c] + dc[c];
+    {   // every edge must appear exactly once; derive chk_equ_idx (VN of each check edge)
+        std::vector<int> edge_vn((size_t)d->E);
+        for (int v = 0; v < nvar; v++) for (int e = d->vn_ptr[(size_t)v]; e < d->vn_ptr[(size_t)v + 1]; e++) edge_vn[(size_t)e] = v;
+        std::vector<uint8_t> seen((size_t)d->E, 0);
+        d->cn_vn.resize((size_t)d->E);
+        for (int k = 0; k < d->E; k++) {
+            int e = cn_msg_idx[k];
+            if (e < 0 || e >= d->E || seen[(size_t)e]) return fail(LUTLDPC_ERR_ARG, "cn_msg_idx is not a permutation of the edges");
+            seen[(size_t)e] = 1;
+            d->cn_vn[(size_t)k] = edge_vn[(size_t)e];
+        }
+    }
+    build_classes(d->dv, d->vclass, d->vn_list);
+    build_classes(d->dc, d->cclass, d->cn_list);
+    d->Nq_Cha = Nq_Cha; d->Nq_Msg.assign(Nq_Msg, Nq_Msg + max_iters);
+    d->max_iters_created = d->max_iters = max_iters; d->psc = 1; d->pisc = 0; d->min_lut = min_lut ? 1 : 0;
+    d->iter_set.resize((size_t)max_iters);
+    { int cum = 0; for (int i = 0; i < max_iters; i++) { cum += reuse_vec[i] ? 0 : 1; d->iter_set[(size_t)i] = cum - 1; } }
+    std::string err;
+    if (!parse_tree_array(var_trees_txt, d->var_trees, err)) return fail(LUTLDPC_ERR_PARSE, "var_trees_txt: " + err);
+    if (!d->min_lut) {
+        if (!chk_trees_txt || !parse_tree_array(chk_trees_txt, d->chk_trees, err)) return fail(LUTLDPC_ERR_PARSE, "chk_trees_txt: " + err);
+    }
+    if (const char *e = getenv("LUTLDPC_NODES_PER_BLOCK")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_block = v; }
+    if (const char *e = getenv("LUTLDPC_USE_FAST")) d->use_fast = atoi(e) ? 1 : 0;
+    int rc = compile_all(d.get());
+    if (rc) return rc;
+    d->device = device;
+    if (device >= 0) { rc = upload_static(d.get()); if (rc) return rc; }
+    make_describe(d.get());
+    *out = d.release();
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_destroy(lutldpc_decoder *d) {
+    if (!d) return LUTLDPC_OK;
+    if (d->device >= 0) {
+        (void)hipSetDevice(d->device);
+        if (d->stream) (void)hipStreamSynchronize(d->stream);
+        for (auto &e : d->ev_live) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto &e : d->ev_pool) (void)hipEventDestroy(e);
+        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release();
+        d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
+        d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
+        d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release();
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+    }
+    delete d;
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_set_exit_conditions(lutldpc_decoder *d, int max_iters, int psc, int pisc) {
+    if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
+    if (max_iters < 1 || max_iters > d->max_iters_created) return fail(LUTLDPC_ERR_ARG, "max_iters outside [1, value at creation]");
+    if (!d->dec_plan[(size_t)d->iter_set[(size_t)(max_iters - 1)]].valid)
+        return fail(LUTLDPC_ERR_ARG, "the tree set of iteration max_iters-1 is not a decision tree set");
+    d->max_iters = max_iters; d->psc = psc ? 1 : 0; d->pisc = pisc ? 1 : 0;
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_decode_batch_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B,
+                                        uint8_t *d_out_bits, int32_t *d_out_iters, int sync) {
+    if (!d || !d_cha || !d_msg0 || !d_out_bits || !d_out_iters) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    int rc = decode_device(d, d_cha, d_msg0, B, d_out_bits, d_out_iters);
+    if (rc) return rc;
+    if (sync) HIP_TRY(hipStreamSynchronize(d->stream));
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_decode_batch(lutldpc_decoder *d, const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *out_bits, int32_t *out_iters) {
+    if (!d || !cha || !msg0 || !out_bits || !out_iters) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
+    HIP_TRY(hipSetDevice(d->device));
+    size_t n = (size_t)B * (size_t)d->nvar;
+    HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n)); HIP_TRY(d->d_out_bits.alloc(n)); HIP_TRY(d->d_out_iters.alloc((size_t)B));
+    HIP_TRY(hipMemcpyAsync(d->d_in_cha.p, cha, n, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->d_in_msg.p, msg0, n, hipMemcpyHostToDevice, d->stream));
+    int rc = decode_device(d, d->d_in_cha.p, d->d_in_msg.p, B, d->d_out_bits.p, d->d_out_iters.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_bits, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(out_iters, d->d_out_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int B, const double *qb_Cha, int n_qb_Cha,
+                                     const double *qb_Msg, int n_qb_Msg, int mode, const int32_t *map,
+                                     uint8_t *out_bits, int32_t *out_iters) {
+    if (!d || !llr || !qb_Cha || !out_bits || !out_iters) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
+    if (n_qb_Cha != d->Nq_Cha - 1) return fail(LUTLDPC_ERR_ARG, "qb_Cha must hold Nq_Cha-1 boundaries");
+    if (mode == 0 && (!qb_Msg || n_qb_Msg != d->Nq_Msg[0] - 1)) return fail(LUTLDPC_ERR_ARG, "qb_Msg must hold Nq_Msg[0]-1 boundaries");
+    if (mode == 1 && !map) return fail(LUTLDPC_ERR_ARG, "QCHA mode needs cha2msg_map");
+    if (mode != 0 && mode != 1) return fail(LUTLDPC_ERR_ARG, "initial_message_mode must be 0 (CONT) or 1 (QCHA)");   // src/LDPC_Code_LUT.cpp:218-220
+    HIP_TRY(hipSetDevice(d->device));
+    size_t n = (size_t)B * (size_t)d->nvar;
+    HIP_TRY(d->d_llr.alloc(n)); HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n)); HIP_TRY(d->d_out_bits.alloc(n)); HIP_TRY(d->d_out_iters.alloc((size_t)B));
+    HIP_TRY(d->d_qb_cha.alloc((size_t)n_qb_Cha)); HIP_TRY(d->d_qb_msg.alloc((size_t)(n_qb_Msg > 0 ? n_qb_Msg : 1))); HIP_TRY(d->d_map.alloc((size_t)d->Nq_Cha));
+    HIP_TRY(hipMemcpyAsync(d->d_llr.p, llr, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->d_qb_cha.p, qb_Cha, sizeof(double) * (size_t)n_qb_Cha, hipMemcpyHostToDevice, d->stream));
+    if (mode == 0) HIP_TRY(hipMemcpyAsync(d->d_qb_msg.p, qb_Msg, sizeof(double) * (size_t)n_qb_Msg, hipMemcpyHostToDevice, d->stream));
+    else HIP_TRY(hipMemcpyAsync(d->d_map.p, map, sizeof(int32_t) * (size_t)d->Nq_Cha, hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(quantize_llr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->d_llr.p, n, d->d_qb_cha.p, n_qb_Cha,
+                       d->d_qb_msg.p, n_qb_Msg, mode, d->d_map.p, d->d_in_cha.p, d->d_in_msg.p);
+    LAUNCH_CHECK();
+    int rc = decode_device(d, d->d_in_cha.p, d->d_in_msg.p, B, d->d_out_bits.p, d->d_out_iters.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_bits, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(out_iters, d->d_out_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LUTLDPC_OK;
+}
+
+void *lutldpc_decoder_stream(lutldpc_decoder *d) { return d ? (void *)d->stream : nullptr; }
+
+int lutldpc_decoder_set_profiling(lutldpc_decoder *d, int enable) {
+    if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
+    if (!enable && d->device >= 0) prof_fold(d);
+    d->profiling = enable != 0;
+    return LUTLDPC_OK;
+}
+int lutldpc_decoder_get_profile(lutldpc_decoder *d, int kind, double *total_ms, int64_t *launches) {
+    if (!d || kind < 0 || kind >= LUTLDPC_K_COUNT) return fail(LUTLDPC_ERR_ARG, "bad kind");
+    if (d->device >= 0) prof_fold(d);
+    if (total_ms) *total_ms = d->prof_ms[kind];
+    if (launches) *launches = d->prof_n[kind];
+    return LUTLDPC_OK;
+}
+int lutldpc_decoder_reset_profile(lutldpc_decoder *d) {
+    if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
+    if (d->device >= 0) prof_fold(d);
+    for (int i = 0; i < LUTLDPC_K_COUNT; i++) { d->prof_ms[i] = 0; d->prof_n[i] = 0; }
+    return LUTLDPC_OK;
+}
+int64_t lutldpc_decoder_device_bytes(lutldpc_decoder *d) {
+    if (!d) return 0;
+    return (int64_t)(d->d_msgs.bytes() + d->d_cha_t.bytes() + d->d_msg0_t.bytes() + d->d_hard.bytes() + d->d_state.bytes() + d->d_vfail.bytes() +
+                     d->d_iters.bytes() + d->d_in_cha.bytes() + d->d_in_msg.bytes() + d->d_out_bits.bytes() + d->d_out_iters.bytes() + d->d_llr.bytes() +
+                     d->d_ops.bytes() + d->d_tables.bytes() + d->d_cn_idx.bytes() + d->d_cn_vn.bytes());
+}
+const char *lutldpc_decoder_describe(lutldpc_decoder *d) { return d ? d->describe.c_str() : ""; }
+
+static const Program *find_prog(lutldpc_decoder *d, int kind, int set, int cls) {
+    auto &v = kind == TT_VAR ? d->var_prog : kind == TT_CHK ? d->chk_prog : d->dec_prog;
+    if (set < 0 || set >= (int)v.size() || cls < 0 || cls >= (int)v[(size_t)set].size()) return nullptr;
+    return &v[(size_t)set][(size_t)cls];
+}
+int lutldpc_selftest_program_eval(lutldpc_decoder *d, int kind, int set, int cls, const int32_t *in, int n_in, int32_t *out, int n_out) {
+    if (!d || !in || !out) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    const Program *p = find_prog(d, kind, set, cls);
+    if (!p) return fail(LUTLDPC_ERR_ARG, "no such program");
+    if (n_in != p->n_in || n_out != p->n_out) return fail(LUTLDPC_ERR_ARG, "program arity mismatch");
+    if (!eval_program(*p, in, out)) return fail(LUTLDPC_ERR_ARG, "input label outside its alphabet");
+    return LUTLDPC_OK;
+}
+int lutldpc_selftest_program_stats(lutldpc_decoder *d, int kind, int set, int cls, int32_t *n_ops, int32_t *n_ops_naive, int32_t *n_slots) {
+    if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
+    const Program *p = find_prog(d, kind, set, cls);
+    if (!p) return fail(LUTLDPC_ERR_ARG, "no such program");
+    if (n_ops) *n_ops = (int32_t)p->ops.size();
+    if (n_ops_naive) *n_ops_naive = p->n_ops_naive;
+    if (n_slots) *n_slots = p->n_slots;
+    return LUTLDPC_OK;
+}
+
+}  // extern "C"

@@ -83,3 +83,23 @@ int or_api_de_threshold(const int *dl, const double *l, int nl, const int *dr, c
     or_de_lut_free(de); or_tree_array_free(var_t); or_tree_array_free(chk_t); or_ensemble_free(ens); free(Nq);
     return it;
 }
+
+/* evaluate tree [set][cls] of the codec for one node (tests of the product's tree compiler) */
+int or_api_codec_tree_eval(const or_codec *c, int kind, int set, int cls, const int *in, int n_in, int *out)
+{
+    const or_tree_array *a = (kind == OR_CHKTREE) ? c->chk_trees : c->var_trees;
+    if (!a || set < 0 || set >= a->n_sets || cls < 0 || cls >= a->n_classes[set]) return -1;
+    const or_tree *t = a->t[set][cls];
+    if (kind == OR_VARTREE) or_tree_var_msg_update(t, in, n_in - 1, in[n_in - 1], out);
+    else if (kind == OR_CHKTREE) or_tree_chk_msg_update(t, in, n_in, out);
+    else out[0] = or_tree_dec_update(t, in, n_in - 1, in[n_in - 1]);
+    return 0;
+}
+int or_api_codec_tree_info(const or_codec *c, int kind, int set, int cls, int *type, int *num_leaves)
+{
+    const or_tree_array *a = (kind == OR_CHKTREE) ? c->chk_trees : c->var_trees;
+    if (!a || set < 0 || set >= a->n_sets || cls < 0 || cls >= a->n_classes[set]) return -1;
+    *type = a->t[set][cls]->type; *num_leaves = a->t[set][cls]->num_leaves;
+    return 0;
+}
+int or_api_codec_n_sets(const or_codec *c, int chk) { const or_tree_array *a = chk ? c->chk_trees : c->var_trees; return a ? a->n_sets : 0; }

@@ -60,6 +60,9 @@ def lib() -> C.CDLL:
             "or_api_codec_chk_tree_txt": (vp, [vp]),
             "or_api_codec_qb": (C.c_int, [vp, C.c_int, dp]),
             "or_api_codec_cha2msg_map": (C.c_int, [vp, ip]),
+            "or_api_codec_tree_eval": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip]),
+            "or_api_codec_tree_info": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, ip]),
+            "or_api_codec_n_sets": (C.c_int, [vp, C.c_int]),
             "or_api_quant_nonlin_vec": (None, [dp, C.c_int, dp, C.c_int, u8p]),
             "or_api_de_threshold": (C.c_int, [ip, dp, C.c_int, ip, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, cp, cp,
                                               C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, dp]),
@@ -213,6 +216,22 @@ class Codec:
         lib().or_codec_lut_decode_batch_u8(self._h, _u8p(cha), _u8p(msg0), B, _u8p(out),
                                            iters.ctypes.data_as(C.POINTER(C.c_int32)))
         return out, iters
+
+    def tree_eval(self, kind: int, tree_set: int, cls: int, inputs, n_out: int) -> np.ndarray:
+        a = np.ascontiguousarray(inputs, np.int32)
+        out = np.zeros(n_out, np.int32)
+        if lib().or_api_codec_tree_eval(self._h, kind, tree_set, cls, _ip(a), len(a), _ip(out)) != 0:
+            raise IndexError("no such tree")
+        return out
+
+    def tree_info(self, kind: int, tree_set: int, cls: int):
+        t, n = C.c_int(), C.c_int()
+        if lib().or_api_codec_tree_info(self._h, kind, tree_set, cls, t, n) != 0:
+            raise IndexError("no such tree")
+        return t.value, n.value
+
+    def n_sets(self, chk=False) -> int:
+        return lib().or_api_codec_n_sets(self._h, int(chk))
 
     def syndrome_ok(self, bits: np.ndarray) -> bool:
         b = np.ascontiguousarray(bits, np.uint8)

@@ -1,0 +1,83 @@
+"""Shared helpers for the parity tests.  The ORACLE (oracle/) is the checker; the product is
+lut_ldpc_amd.  Both sides always receive the *same* label arrays (never rely on
+cross-platform float RNG equality)."""
+from __future__ import annotations
+
+import functools
+from pathlib import Path
+
+import numpy as np
+
+from oracle import oracle as orc
+
+ROOT = Path(__file__).resolve().parent.parent
+CODES = ROOT / "data" / "codes"
+TREES = ROOT / "data" / "trees"
+
+# name -> (alist, design kwargs)
+CONFIGS = {
+    # C1 of BASELINE.json: params/ber.ini.irregular.example
+    "n500_q4": ("rate0.50_dv02-17_dc08-09_lut_q4_N500", dict(sigma2=0.88 ** 2, max_iters=50, nq_cha=16, nq_msg=16)),
+    "n500_q4_i8": ("rate0.50_dv02-17_dc08-09_lut_q4_N500", dict(sigma2=0.88 ** 2, max_iters=8, nq_cha=16, nq_msg=16)),
+    "reg36_n1000_q4": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.88 ** 2, max_iters=20, nq_cha=16, nq_msg=16)),
+    # non-uniform message resolution + LUT reuse (SURVEY step 5)
+    "reg36_n1000_mixed": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.82 ** 2, max_iters=12, nq_cha=16,
+                                                           nq_msg=[16, 16, 16, 8, 8, 8, 8, 8, 8, 8, 8, 8],
+                                                           reuse_vec=[0, 1, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0])),
+    "reg36_n1000_q3_chklut": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.80 ** 2, max_iters=10, nq_cha=16, nq_msg=8, min_lut=False)),
+    "reg36_n1000_rootonly": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.85 ** 2, max_iters=6, nq_cha=8, nq_msg=8, tree_method="root_only")),
+    "reg36_n1000_high": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.85 ** 2, max_iters=6, nq_cha=16, nq_msg=16, tree_method="auto_bin_high")),
+    # C5 of BASELINE.json: params/ber.ini.regular.example (design_SNRdB 3.9, R = 1 - 325/2048)
+    "c5_minlut": ("rate0.84_reg_v6c32_N2048", dict(sigma2=None, design_snr_db=3.9, max_iters=8, nq_cha=16, nq_msg=8,
+                                                   tree_method="filename=" + str(TREES / "6_32_wide.ini"), rank=325)),
+    "c5_chklut": ("rate0.84_reg_v6c32_N2048", dict(sigma2=None, design_snr_db=3.9, max_iters=8, nq_cha=16, nq_msg=8, min_lut=False,
+                                                   tree_method="filename=" + str(TREES / "6_32_wide.ini"), rank=325)),
+    # C2 / C3 of BASELINE.json
+    "reg36_n10000_q4": ("rate0.50_dv03_dc06_N10000", dict(sigma2=0.88 ** 2, max_iters=50, nq_cha=16, nq_msg=16)),
+    "dvbs2_q4": ("rate0.50_irreg_dvbs2_N64800", dict(sigma2=0.88 ** 2, max_iters=50, nq_cha=16, nq_msg=16, allow_deg1=True)),
+    "dvbs2_q4_i6": ("rate0.50_irreg_dvbs2_N64800", dict(sigma2=0.88 ** 2, max_iters=6, nq_cha=16, nq_msg=16, allow_deg1=True)),
+    "twin64800_q4_i6": ("rate0.50_dv02-08_dc07-08_lut_q4_N64800", dict(sigma2=0.88 ** 2, max_iters=6, nq_cha=16, nq_msg=16)),
+}
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_codec(name: str):
+    """Load the alist and design the LUTs with the oracle (cached per test session)."""
+    alist, kw = CONFIGS[name]
+    kw = dict(kw)
+    code = orc.Code(CODES / f"{alist}.alist")
+    cd = orc.Codec(code, skip_rank=True)
+    rank = kw.pop("rank", code.nchk)
+    cd.set_rank(rank)
+    max_iters = kw.pop("max_iters")
+    nq = kw.pop("nq_msg")
+    nq_msg = np.full(max_iters, nq, np.int32) if np.isscalar(nq) else np.asarray(nq, np.int32)
+    snr = kw.pop("design_snr_db", None)
+    sigma2 = kw.pop("sigma2")
+    if sigma2 is None:   # src/LDPC_BER_Sim.cpp:482
+        rate = 1.0 - rank / code.nvar
+        sigma2 = 10 ** (-snr / 10) / (2 * rate)
+    cd.design_luts(sigma2=sigma2, max_iters=max_iters, nq_msg=nq_msg, **kw)
+    cd.rate = 1.0 - rank / code.nvar
+    return cd
+
+
+def product_decoder(cd, device=0):
+    """Build the product's decoder from the oracle-designed tables (the reference's own tree text)."""
+    import lut_ldpc_amd as L
+    c = cd.code
+    chk = "" if cd.min_lut else cd.chk_tree_txt
+    return L.Decoder(c.nvar, c.nchk, c.dv, c.dc, c.cn_msg_idx, cd.nq_cha, cd.nq_msg, cd.reuse_vec, cd.max_iters, cd.min_lut,
+                     cd.var_tree_txt, chk, device=device)
+
+
+def awgn_labels(cd, B, snr_db, seed, mode=0):
+    """All-zero codeword over BPSK/AWGN, LLR = 4x/N0 (src/LDPC_BER_Sim.cpp:248-278), quantised with the
+    designed boundaries (src/LDPC_Code_LUT.cpp:207-221).  Returns (cha, msg0) uint8 [B, nvar]."""
+    rng = np.random.default_rng(seed)
+    N0 = 10 ** (-snr_db / 10) / cd.rate
+    x = 1.0 + rng.normal(0.0, np.sqrt(N0 / 2), (B, cd.code.nvar))
+    llr = 4 * x / N0
+    cha = orc.quant_nonlin(llr, cd.qb_cha)
+    msg = orc.quant_nonlin(llr, cd.qb_msg) if mode == 0 else cd.cha2msg_map[cha].astype(np.uint8)
+    return cha, msg, llr

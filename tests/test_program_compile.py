@@ -1,0 +1,74 @@
+"""The product's tree compiler (value sharing, slot allocation, full-table expansion) against the
+oracle's faithful queue/recursion evaluation, without a GPU: lutldpc_selftest_program_eval."""
+import numpy as np
+import pytest
+
+from helpers import oracle_codec, product_decoder
+
+VAR, CHK, DEC = 0, 1, 2
+
+
+def _check(cd, dec, kind, tree_set, cls, deg, n_trials, rng, k_in, k_cha):
+    n_in = deg if kind == CHK else deg + 1
+    n_out = 1 if kind == DEC else deg
+    for _ in range(n_trials):
+        x = rng.integers(0, k_in, n_in).astype(np.int32)
+        if kind != CHK:
+            x[-1] = rng.integers(0, k_cha)
+        want = cd.tree_eval(kind, tree_set, cls, x, n_out)
+        got = dec.program_eval(kind, tree_set, cls, x, n_out)
+        assert (want == got).all(), (kind, tree_set, cls, x, want, got)
+
+
+@pytest.mark.parametrize("name", ["n500_q4_i8", "reg36_n1000_mixed", "reg36_n1000_q3_chklut", "reg36_n1000_rootonly",
+                                  "reg36_n1000_high", "c5_chklut"])
+def test_programs_match_oracle_tree_walk(name):
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)      # host-only handle: no GPU needed for the compile step
+    rng = np.random.default_rng(11)
+    degs_v = sorted(set(cd.code.dv.tolist()))
+    degs_c = sorted(set(cd.code.dc.tolist()))
+    n_sets = cd.n_sets()
+    set_iters = np.flatnonzero(np.asarray(cd.reuse_vec) == 0)      # first iteration using each tree set
+    for s in range(n_sets):
+        it = int(set_iters[s])
+        k_in = int(cd.nq_msg[it])
+        kind = DEC if s == n_sets - 1 else VAR
+        for cls, dv in enumerate(degs_v):
+            _check(cd, dec, kind, s, cls, dv, 40, rng, k_in, cd.nq_cha)
+        if not cd.min_lut:
+            for cls, dc in enumerate(degs_c):
+                _check(cd, dec, CHK, s, cls, dc, 25, rng, k_in, cd.nq_cha)
+    dec.close()
+
+
+def test_value_sharing_counts():
+    """a subtree over L leaves has only L+1 distinct input tuples over all outputs."""
+    cd = oracle_codec("n500_q4_i8")
+    dec = product_decoder(cd, device=-1)
+    stats = {dv: dec.program_stats(VAR, 0, cls) for cls, dv in enumerate([2, 3, 9, 17])}
+    assert stats[17]["ops_naive"] == 17 * 16 and stats[17]["ops"] == 96
+    assert stats[9]["ops_naive"] == 9 * 8 and stats[9]["ops"] == 40
+    assert stats[3]["ops"] == 6 and stats[2]["ops"] == 2
+    dec.close()
+
+
+def test_create_rejects_bad_input():
+    import lut_ldpc_amd as L
+    cd = oracle_codec("n500_q4_i8")
+    c = cd.code
+    bad = c.cn_msg_idx.copy(); bad[0] = bad[1]
+    with pytest.raises(L.LutLdpcError):
+        L.Decoder(c.nvar, c.nchk, c.dv, c.dc, bad, 16, cd.nq_msg, cd.reuse_vec, 8, True, cd.var_tree_txt, "", device=-1)
+    with pytest.raises(L.LutLdpcError):
+        L.Decoder(c.nvar, c.nchk, c.dv, c.dc, c.cn_msg_idx, 16, cd.nq_msg, cd.reuse_vec, 8, True, "3\n1\n0 2", "", device=-1)
+    reuse = np.array(cd.reuse_vec); reuse[0] = 1      # src/LDPC_Code_LUT.cpp:122
+    with pytest.raises(L.LutLdpcError):
+        L.Decoder(c.nvar, c.nchk, c.dv, c.dc, c.cn_msg_idx, 16, cd.nq_msg, reuse, 8, True, cd.var_tree_txt, "", device=-1)
+    d = product_decoder(cd, device=-1)
+    with pytest.raises(L.LutLdpcError) as e:       # no device -> loud failure, never a CPU decode
+        d.lut_decode_batch(np.zeros((1, c.nvar), np.uint8), np.zeros((1, c.nvar), np.uint8))
+    assert e.value.code == -5
+    with pytest.raises(L.LutLdpcError):            # iteration 3 is not a decision-tree set
+        d.set_exit_conditions(3)
+    d.close()
