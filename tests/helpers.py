@@ -33,7 +33,7 @@ CONFIGS = {
     "c5_chklut": ("rate0.84_reg_v6c32_N2048", dict(sigma2=None, design_snr_db=3.9, max_iters=8, nq_cha=16, nq_msg=8, min_lut=False,
                                                    tree_method="filename=" + str(TREES / "6_32_wide.ini"), rank=325)),
     # C2 / C3 of BASELINE.json
-    "reg36_n10000_q4": ("rate0.50_dv03_dc06_N10000", dict(sigma2=0.88 ** 2, max_iters=50, nq_cha=16, nq_msg=16)),
+    "reg36_n10000_q4": ("rate0.50_dv03_dc06_N10000", dict(sigma2=0.84 ** 2, max_iters=50, nq_cha=16, nq_msg=16)),
     "dvbs2_q4": ("rate0.50_irreg_dvbs2_N64800", dict(sigma2=0.88 ** 2, max_iters=50, nq_cha=16, nq_msg=16, allow_deg1=True)),
     "dvbs2_q4_i6": ("rate0.50_irreg_dvbs2_N64800", dict(sigma2=0.88 ** 2, max_iters=6, nq_cha=16, nq_msg=16, allow_deg1=True)),
     "twin64800_q4_i6": ("rate0.50_dv02-08_dc07-08_lut_q4_N64800", dict(sigma2=0.88 ** 2, max_iters=6, nq_cha=16, nq_msg=16)),

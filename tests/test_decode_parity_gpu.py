@@ -102,7 +102,7 @@ def test_full_size_properties_c2():
     cd = oracle_codec("reg36_n10000_q4")
     dec = product_decoder(cd)
     B = 4096
-    cha, msg, _ = awgn_labels(cd, B, 1.7, seed=42)
+    cha, msg, _ = awgn_labels(cd, B, 1.8, seed=42)
     dec.set_exit_conditions(50, True, True)
     bits, it = dec.lut_decode_batch(cha, msg)
     ok = it > 0
