@@ -1,0 +1,68 @@
+/*
+ * lut_ldpc_host.h -- C-ABI over the C++ host mirror of the reference's LDPC_Code_LUT /
+ * LDPC_BER_Sim_LUT (lut_ldpc_amd/csrc/host), so that non-C++ callers (the Python tests and
+ * bench.py, a cgo/JNI binding, ...) can drive the same objects ber_sim uses.
+ *
+ * A `lutldpc_codec` bundles what LDPC_BER_Sim_LUT::load builds (src/LDPC_BER_Sim.cpp:434-550):
+ * the parity-check matrix (alist), optionally the systematic generator, and the
+ * LDPC_Code_LUT object whose decode path runs on the MI355X (include/lut_ldpc_hip.h).
+ * Return codes and lutldpc_last_error() as in lut_ldpc_hip.h.
+ */
+#ifndef LUT_LDPC_HOST_H
+#define LUT_LDPC_HOST_H
+
+#include "lut_ldpc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lutldpc_codec lutldpc_codec;
+
+/* new LDPC_Parity(alist) [+ LDPC_Generator_Systematic(H)] + new LDPC_Code_LUT(H, G)
+ * (src/LDPC_BER_Sim.cpp:443-476).  known_rank > 0 skips the GF(2) rank computation.
+ * device = -1 gives a host-only object (LUT design, files) that cannot decode. */
+int lutldpc_codec_create(const char *alist_path, int with_generator, int known_rank, int device, lutldpc_codec **out);
+/* LDPC_Code_LUT(filename, G): load a lut_codec.it (src/LDPC_Code_LUT.cpp:568-641) */
+int lutldpc_codec_load(const char *codec_path, int device, lutldpc_codec **out);
+int lutldpc_codec_save(lutldpc_codec *c, const char *codec_path);     /* save_code, :643-697 */
+int lutldpc_codec_destroy(lutldpc_codec *c);
+
+/* LDPC_Code_LUT::design_luts with the empirical ensemble of H (src/LDPC_Code_LUT.cpp:699-746,
+ * src/LDPC_BER_Sim.cpp:487-495).  allow_degree_one: build-side extension for degree-1 VNs. */
+int lutldpc_codec_design_luts(lutldpc_codec *c, const char *tree_method, int min_lut, double sigma2, int max_iters,
+                              const uint8_t *reuse_vec, int Nq_Cha, const int32_t *Nq_Msg, int allow_degree_one,
+                              double *sigma_out);
+int lutldpc_codec_set_exit_conditions(lutldpc_codec *c, int max_iters, int psc, int pisc);
+int lutldpc_codec_set_initial_message_mode(lutldpc_codec *c, int mode);   /* 0 CONT, 1 QCHA */
+int lutldpc_codec_set_output_verbosity(lutldpc_codec *c, int level);
+
+/* getters */
+int lutldpc_codec_dims(lutldpc_codec *c, int32_t *nvar, int32_t *nchk, int32_t *nedges, int32_t *rank);
+int lutldpc_codec_graph(lutldpc_codec *c, int32_t *dv, int32_t *dc, int32_t *cn_msg_idx);
+/* text of the tree arrays; returns the length needed (incl. NUL); copies when cap suffices */
+int64_t lutldpc_codec_var_trees_txt(lutldpc_codec *c, char *buf, int64_t cap);
+int64_t lutldpc_codec_chk_trees_txt(lutldpc_codec *c, char *buf, int64_t cap);
+int lutldpc_codec_qb(lutldpc_codec *c, int which /*0 Cha, 1 Msg*/, double *out, int cap);   /* returns count */
+int lutldpc_codec_cha2msg_map(lutldpc_codec *c, int32_t *out, int cap);                       /* returns count */
+double lutldpc_codec_rate(lutldpc_codec *c);
+/* the underlying HIP decoder (created on first use; NULL + error when there is no device) */
+lutldpc_decoder *lutldpc_codec_decoder(lutldpc_codec *c);
+
+/* batched LDPC_Code_LUT::decode / lut_decode (host buffers, all nvar bits per frame) */
+int lutldpc_codec_decode_llr_batch(lutldpc_codec *c, const double *llr, int B, uint8_t *bits, int32_t *iters);
+int lutldpc_codec_lut_decode_batch(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters);
+/* LDPC_Code_LUT::encode: info[K] -> codeword[nvar] (needs with_generator) */
+int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codeword);
+
+/* LDPC_DE_LUT::bisec_search for an ensemble given by its active degrees (prog/de_sim.cpp:137-260
+ * set-up: auto trees, no reuse, uniform resolution).  Returns the bisection count, <0 on error. */
+int lutldpc_de_threshold(const int32_t *dl, const double *lam, int nl, const int32_t *dr, const double *rho, int nr,
+                         int qbits_cha, int qbits_msg, int maxiter_de, int min_lut, const char *tree_mode, const char *strategy,
+                         double thr_min, double thr_prec, double Pe_max, int maxiter_bisec, int max_ni_de_iters,
+                         double LLR_max, int Nq_fine, double *thr_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

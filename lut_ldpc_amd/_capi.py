@@ -72,3 +72,32 @@ def check(rc: int) -> None:
 
 def device_count() -> int:
     return lib.lutldpc_device_count()
+
+# ---- host mirror (include/lut_ldpc_host.h) ---------------------------------------------------
+_HOST_SIGNATURES = {
+    "lutldpc_codec_create": (C.c_int, [_cp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lutldpc_codec_load": (C.c_int, [_cp, C.c_int, C.POINTER(_vp)]),
+    "lutldpc_codec_save": (C.c_int, [_vp, _cp]),
+    "lutldpc_codec_destroy": (C.c_int, [_vp]),
+    "lutldpc_codec_design_luts": (C.c_int, [_vp, _cp, C.c_int, C.c_double, C.c_int, _u8p, C.c_int, _ip, C.c_int, _dp]),
+    "lutldpc_codec_set_exit_conditions": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "lutldpc_codec_set_initial_message_mode": (C.c_int, [_vp, C.c_int]),
+    "lutldpc_codec_set_output_verbosity": (C.c_int, [_vp, C.c_int]),
+    "lutldpc_codec_dims": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "lutldpc_codec_graph": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "lutldpc_codec_var_trees_txt": (C.c_int64, [_vp, C.c_char_p, C.c_int64]),
+    "lutldpc_codec_chk_trees_txt": (C.c_int64, [_vp, C.c_char_p, C.c_int64]),
+    "lutldpc_codec_qb": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "lutldpc_codec_cha2msg_map": (C.c_int, [_vp, _ip, C.c_int]),
+    "lutldpc_codec_rate": (C.c_double, [_vp]),
+    "lutldpc_codec_decoder": (_vp, [_vp]),
+    "lutldpc_codec_decode_llr_batch": (C.c_int, [_vp, _dp, C.c_int, _u8p, _ip]),
+    "lutldpc_codec_lut_decode_batch": (C.c_int, [_vp, _u8p, _u8p, C.c_int, _u8p, _ip]),
+    "lutldpc_codec_encode": (C.c_int, [_vp, _u8p, _u8p]),
+    "lutldpc_de_threshold": (C.c_int, [_ip, _dp, C.c_int, _ip, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _cp, _cp, C.c_double,
+                                       C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, _dp]),
+}
+for _name, (_res, _args) in _HOST_SIGNATURES.items():
+    if hasattr(lib, _name):
+        _fn = getattr(lib, _name)
+        _fn.restype, _fn.argtypes = _res, _args

@@ -429,6 +429,8 @@ void make_describe(lutldpc_decoder *d) {
 extern "C" {
 
 const char *lutldpc_last_error(void) { return g_err.c_str(); }
+// used by the host mirror (host_capi.cpp) to report through the same channel
+void lutldpc_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 const char *lutldpc_version(void) { return "lut_ldpc_amd 0.1 gfx950"; }
 
 int lutldpc_device_count(void) {

@@ -1,0 +1,173 @@
+// host_capi.cpp -- C-ABI of include/lut_ldpc_host.h over the C++ host classes.
+#include "lut_ldpc_host.h"
+#include "ldpc_code_lut.hpp"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+using namespace lut_ldpc;
+
+struct lutldpc_codec {
+    std::unique_ptr<LDPC_Parity> H;
+    std::unique_ptr<LDPC_Generator_Systematic> G;
+    std::unique_ptr<LDPC_Code_LUT> C;
+};
+
+extern "C" void lutldpc_set_last_error(const char *msg);   // decoder.hip
+
+namespace {
+template <class F>
+int guarded(F &&f) {
+    try { return f(); }
+    catch (const std::invalid_argument &e) { lutldpc_set_last_error(e.what()); return LUTLDPC_ERR_ARG; }
+    catch (const std::logic_error &e) { lutldpc_set_last_error(e.what()); return LUTLDPC_ERR_STATE; }
+    catch (const std::exception &e) { lutldpc_set_last_error(e.what()); return LUTLDPC_ERR_ARG; }
+}
+int64_t copy_out(const std::string &s, char *buf, int64_t cap) {
+    const int64_t need = (int64_t)s.size() + 1;
+    if (buf && cap >= need) std::memcpy(buf, s.c_str(), (size_t)need);
+    return need;
+}
+}  // namespace
+
+extern "C" {
+
+int lutldpc_codec_create(const char *alist_path, int with_generator, int known_rank, int device, lutldpc_codec **out) {
+    return guarded([&] {
+        if (!alist_path || !out) throw std::invalid_argument("NULL argument");
+        std::unique_ptr<lutldpc_codec> c(new lutldpc_codec);
+        c->H.reset(new LDPC_Parity(alist_path));
+        if (with_generator) c->G.reset(new LDPC_Generator_Systematic(c->H.get()));
+        c->C.reset(new LDPC_Code_LUT());
+        c->C->set_device(device);
+        // known_rank > 0: rank(H) supplied by the caller (dense elimination of a 64800-column
+        // code takes minutes; the reference pays that price at every start-up)
+        c->C->set_code_with_rank(c->H.get(), c->G.get(), known_rank);
+        *out = c.release();
+        return LUTLDPC_OK;
+    });
+}
+
+int lutldpc_codec_load(const char *codec_path, int device, lutldpc_codec **out) {
+    return guarded([&] {
+        if (!codec_path || !out) throw std::invalid_argument("NULL argument");
+        std::unique_ptr<lutldpc_codec> c(new lutldpc_codec);
+        c->G.reset(new LDPC_Generator_Systematic());
+        c->C.reset(new LDPC_Code_LUT(std::string(codec_path), c->G.get()));
+        c->C->set_device(device);
+        *out = c.release();
+        return LUTLDPC_OK;
+    });
+}
+
+int lutldpc_codec_save(lutldpc_codec *c, const char *path) {
+    return guarded([&] { if (!c || !path) throw std::invalid_argument("NULL argument"); c->C->save_code(path); return LUTLDPC_OK; });
+}
+
+int lutldpc_codec_destroy(lutldpc_codec *c) { delete c; return LUTLDPC_OK; }
+
+int lutldpc_codec_design_luts(lutldpc_codec *c, const char *tree_method, int min_lut, double sigma2, int max_iters, const uint8_t *reuse_vec,
+                              int Nq_Cha, const int32_t *Nq_Msg, int allow_degree_one, double *sigma_out) {
+    return guarded([&] {
+        if (!c || !tree_method || !reuse_vec || !Nq_Msg || max_iters < 1) throw std::invalid_argument("NULL / bad argument");
+        if (!c->H) throw std::logic_error("design_luts needs the parity-check matrix (codec was loaded from a codec file)");
+        const bvec reuse(reuse_vec, reuse_vec + max_iters);
+        const ivec nq(Nq_Msg, Nq_Msg + max_iters);
+        const double s = c->C->design_luts(tree_method, get_empirical_ensemble(*c->H), min_lut != 0, sigma2, max_iters, reuse, Nq_Cha, nq, allow_degree_one != 0);
+        if (sigma_out) *sigma_out = s;
+        return LUTLDPC_OK;
+    });
+}
+
+int lutldpc_codec_set_exit_conditions(lutldpc_codec *c, int max_iters, int psc, int pisc) {
+    return guarded([&] { if (!c) throw std::invalid_argument("NULL codec"); c->C->set_exit_conditions(max_iters, psc != 0, pisc != 0); return LUTLDPC_OK; });
+}
+int lutldpc_codec_set_initial_message_mode(lutldpc_codec *c, int mode) {
+    return guarded([&] {
+        if (!c || mode < 0 || mode > 1) throw std::invalid_argument("mode must be 0 (CONT) or 1 (QCHA)");
+        c->C->set_initial_message_mode(mode ? LDPC_Code_LUT::QCHA : LDPC_Code_LUT::CONT);
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_codec_set_output_verbosity(lutldpc_codec *c, int level) {
+    return guarded([&] { if (!c) throw std::invalid_argument("NULL codec"); c->C->set_output_verbosity(level); return LUTLDPC_OK; });
+}
+
+int lutldpc_codec_dims(lutldpc_codec *c, int32_t *nvar, int32_t *nchk, int32_t *nedges, int32_t *rank) {
+    return guarded([&] {
+        if (!c) throw std::invalid_argument("NULL codec");
+        if (nvar) *nvar = c->C->get_nvar();
+        if (nchk) *nchk = c->C->get_nchk();
+        if (nedges) *nedges = (int32_t)c->C->get_cn_msg_idx().size();
+        if (rank) *rank = c->C->get_nchk_lin_indep();
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_codec_graph(lutldpc_codec *c, int32_t *dv, int32_t *dc, int32_t *cn_msg_idx) {
+    return guarded([&] {
+        if (!c || !dv || !dc || !cn_msg_idx) throw std::invalid_argument("NULL argument");
+        std::memcpy(dv, c->C->get_dv_vec().data(), sizeof(int32_t) * c->C->get_dv_vec().size());
+        std::memcpy(dc, c->C->get_dc_vec().data(), sizeof(int32_t) * c->C->get_dc_vec().size());
+        std::memcpy(cn_msg_idx, c->C->get_cn_msg_idx().data(), sizeof(int32_t) * c->C->get_cn_msg_idx().size());
+        return LUTLDPC_OK;
+    });
+}
+int64_t lutldpc_codec_var_trees_txt(lutldpc_codec *c, char *buf, int64_t cap) { return c ? copy_out(to_string(c->C->get_var_trees()), buf, cap) : 0; }
+int64_t lutldpc_codec_chk_trees_txt(lutldpc_codec *c, char *buf, int64_t cap) { return c ? copy_out(to_string(c->C->get_chk_trees()), buf, cap) : 0; }
+int lutldpc_codec_qb(lutldpc_codec *c, int which, double *out, int cap) {
+    if (!c) return 0;
+    const vec &q = which == 0 ? c->C->get_qb_Cha() : c->C->get_qb_Msg();
+    if (out && cap >= (int)q.size()) std::memcpy(out, q.data(), sizeof(double) * q.size());
+    return (int)q.size();
+}
+int lutldpc_codec_cha2msg_map(lutldpc_codec *c, int32_t *out, int cap) {
+    if (!c) return 0;
+    const ivec &m = c->C->get_Nq_Cha_2_Nq_Msg_map();
+    if (out && cap >= (int)m.size()) std::memcpy(out, m.data(), sizeof(int32_t) * m.size());
+    return (int)m.size();
+}
+double lutldpc_codec_rate(lutldpc_codec *c) { return c ? c->C->get_rate() : 0.0; }
+
+lutldpc_decoder *lutldpc_codec_decoder(lutldpc_codec *c) {
+    lutldpc_decoder *d = nullptr;
+    guarded([&] { if (!c) throw std::invalid_argument("NULL codec"); d = c->C->device_handle(); return LUTLDPC_OK; });
+    return d;
+}
+
+int lutldpc_codec_decode_llr_batch(lutldpc_codec *c, const double *llr, int B, uint8_t *bits, int32_t *iters) {
+    return guarded([&] { if (!c || !llr || !bits || !iters) throw std::invalid_argument("NULL argument"); c->C->decode_batch(llr, B, bits, iters); return LUTLDPC_OK; });
+}
+int lutldpc_codec_lut_decode_batch(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters) {
+    return guarded([&] { if (!c || !cha || !msg0 || !bits || !iters) throw std::invalid_argument("NULL argument"); c->C->lut_decode_batch(cha, msg0, B, bits, iters); return LUTLDPC_OK; });
+}
+int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codeword) {
+    return guarded([&] {
+        if (!c || !info || !codeword) throw std::invalid_argument("NULL argument");
+        bvec in(info, info + c->C->get_ninfo()), out;
+        c->C->encode(in, out);
+        std::memcpy(codeword, out.data(), out.size());
+        return LUTLDPC_OK;
+    });
+}
+
+int lutldpc_de_threshold(const int32_t *dl, const double *lam, int nl, const int32_t *dr, const double *rho, int nr, int qbits_cha, int qbits_msg,
+                         int maxiter_de, int min_lut, const char *tree_mode, const char *strategy, double thr_min, double thr_prec, double Pe_max,
+                         int maxiter_bisec, int max_ni_de_iters, double LLR_max, int Nq_fine, double *thr_out) {
+    int iters = -1;
+    int rc = guarded([&] {
+        if (!dl || !lam || !dr || !rho || !tree_mode || !strategy || !thr_out) throw std::invalid_argument("NULL argument");
+        LDPC_Ensemble ens(ivec(dl, dl + nl), vec(lam, lam + nl), ivec(dr, dr + nr), vec(rho, rho + nr));
+        const ivec Nq((size_t)maxiter_de, 1 << qbits_msg);
+        LUT_Tree_Array var_t, chk_t;
+        get_lut_tree_templates(tree_mode, ens, Nq, 1 << qbits_cha, min_lut != 0, var_t, chk_t);
+        LDPC_DE_LUT de(ens, 1 << qbits_cha, Nq, maxiter_de, var_t, chk_t, bvec(), thr_prec, Pe_max, maxiter_bisec, LLR_max, Nq_fine, strategy);
+        de.set_bisec_window(thr_min, rate_to_shannon_thr(ens.get_rate()));
+        de.set_exit_conditions(maxiter_de, maxiter_bisec, max_ni_de_iters, Pe_max, thr_prec);
+        iters = de.bisec_search(*thr_out);
+        return LUTLDPC_OK;
+    });
+    return rc == LUTLDPC_OK ? iters : rc;
+}
+
+}  // extern "C"

@@ -170,7 +170,14 @@ or_dvec or_sym_llr_sort_unique(or_dvec p_in, or_ivec *idx_in, or_ivec *idx_sorte
 {
     int M_in = p_in.n;
     double *llr = (double *)malloc(sizeof(double) * (size_t)M_in);
-    for (int i = 0; i < M_in; i++) llr[i] = log(p_in.v[i]) - log(p_in.v[M_in - 1 - i]);
+    for (int i = 0; i < M_in; i++) {
+        llr[i] = log(p_in.v[i]) - log(p_in.v[M_in - 1 - i]);
+        /* a label pair without any mass gives -inf - -inf = NaN; the reference then sorts NaNs with
+         * a comparison sort (undefined order).  Pinned here: such a pair carries LLR 0, which keeps
+         * the sorted order symmetric.  Only check-node LUT design can reach this (LUT_Tree.cpp:761
+         * does not strip zero-mass labels, unlike :726-728). */
+        if (isnan(llr[i])) llr[i] = 0.0;
+    }
     *idx_in = or_ivec_new(M_in);
     for (int i = 0; i < M_in; i++) idx_in->v[i] = i;
     g_sort_key = llr;

@@ -1,0 +1,89 @@
+"""The product's C++ host mirror (alist, rank, LUT design, codec files) against the oracle.
+Bit-exact: the serialised trees must be the same text, the boundaries the same doubles."""
+import numpy as np
+import pytest
+
+import lut_ldpc_amd as L
+from helpers import CODES, CONFIGS, oracle_codec
+
+
+def product_codec(name, device=-1):
+    alist, kw = CONFIGS[name]
+    kw = dict(kw)
+    rank = kw.pop("rank", None)
+    cd = L.Codec(CODES / f"{alist}.alist", known_rank=rank or (32400 if "64800" in alist else 0), device=device)
+    snr = kw.pop("design_snr_db", None)
+    sigma2 = kw.pop("sigma2")
+    if sigma2 is None:
+        sigma2 = 10 ** (-snr / 10) / (2 * cd.rate)
+    if "allow_deg1" in kw:
+        kw["allow_degree_one"] = kw.pop("allow_deg1")
+    cd.design_luts(sigma2=sigma2, **kw)
+    return cd
+
+
+@pytest.mark.parametrize("name", ["n500_q4_i8", "reg36_n1000_mixed", "reg36_n1000_q3_chklut", "reg36_n1000_rootonly",
+                                  "reg36_n1000_high", "c5_minlut", "c5_chklut", "dvbs2_q4_i6"])
+def test_design_matches_oracle(name):
+    want = oracle_codec(name)
+    got = product_codec(name)
+    assert got.var_trees_txt == want.var_tree_txt
+    if not want.min_lut:
+        assert got.chk_trees_txt == want.chk_tree_txt
+    assert (got.qb_cha == want.qb_cha).all() and (got.qb_msg == want.qb_msg).all()
+    assert (got.cha2msg_map == want.cha2msg_map).all()
+    dv, dc, cn = got.graph()
+    assert (dv == want.code.dv).all() and (dc == want.code.dc).all() and (cn == want.code.cn_msg_idx).all()
+    got.close()
+
+
+def test_rank_and_rate():
+    cd = L.Codec(CODES / "rate0.84_reg_v6c32_N2048.alist", device=-1)
+    assert cd.rank == 325 and f"{cd.rate:g}" == "0.841309"        # README.md:239
+    cd.close()
+    cd = L.Codec(CODES / "rate0.50_dv02-17_dc08-09_lut_q4_N500.alist", device=-1)
+    assert cd.rank == 250 and f"{cd.rate:g}" == "0.5"             # README.md:114
+    cd.close()
+
+
+def test_degree_one_needs_the_extension():
+    cd = L.Codec(CODES / "rate0.50_irreg_dvbs2_N64800.alist", known_rank=32400, device=-1)
+    with pytest.raises(L.LutLdpcError):       # the reference asserts here (src/LUT_Tree.cpp:202)
+        cd.design_luts(max_iters=3)
+    cd.close()
+
+
+def test_generator_makes_codewords():
+    cd = L.Codec(CODES / "rate0.84_reg_v6c32_N2048.alist", with_generator=True, device=-1)
+    assert cd.ninfo == 2048 - 325
+    rng = np.random.default_rng(3)
+    dv, dc, cn = cd.graph()
+    vn_of_edge = np.repeat(np.arange(cd.nvar), dv)      # H rebuilt from the (column-permuted) graph
+    for _ in range(5):
+        info = rng.integers(0, 2, cd.ninfo).astype(np.uint8)
+        cw = cd.encode(info)
+        assert (cw[:cd.ninfo] == info).all()              # systematic, src/LDPC_Code_LUT.cpp:225
+        p = 0
+        for c in range(cd.nchk):
+            assert cw[vn_of_edge[cn[p:p + dc[c]]]].sum() % 2 == 0
+            p += dc[c]
+    cd.close()
+
+
+def test_codec_file_roundtrip(tmp_path):
+    cd = product_codec("n500_q4_i8")
+    path = tmp_path / "lut_codec.it"
+    cd.save(path)
+    raw = path.read_bytes()
+    assert raw[:5] == b"IT++\x03" and b"var_tree_string\x00string\x00" in raw      # scripts/itload.m:48-63
+    cd2 = L.Codec(codec_path=path, device=-1)
+    assert cd2.var_trees_txt == cd.var_trees_txt and (cd2.qb_cha == cd.qb_cha).all()
+    assert (cd2.nvar, cd2.nchk, cd2.rank) == (cd.nvar, cd.nchk, cd.rank)
+    cd.close()
+    cd2.close()
+
+
+@pytest.mark.slow
+def test_de_threshold_readme_product():
+    thr, it = L.de_threshold([2, 3, 9, 17], [0.138045, 0.401038, 0.026586, 0.434331], [8, 9], [0.323376, 0.676624])
+    assert it == 20 and f"{thr:g}" == "0.929193"      # README.md:173-176
