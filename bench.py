@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded codewords/s of the MI355X LUT-LDPC decode path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dvbs2|twin|c2|c1|c5] [--batch B] [--mode fixed|shipped]
+
+A *step* is one pass of the hot path (LDPC_Code_LUT::lut_decode, all iterations) over one batch of
+B frames per GPU whose quantised labels are already resident in HBM.  Default workload: the
+configuration BASELINE.json's metric is quoted on -- rate0.50_irreg_dvbs2_N64800, 4-bit channel and
+message labels, 50 iterations, min-LUT -- in fixed-work mode (parity_check_iter = false: every frame
+runs all 50 iterations, nothing is skipped).  For N > 1 launch through torch.distributed.run: one
+process per GPU, frames sharded (weak scaling), one RCCL all-reduce of the BER/FER counters.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (variable-node LUT pass):
+algorithmic bytes per launch / mean launch duration from HIP events recorded on the decoder's own
+stream inside the timed region.  `cpu_baseline` times the oracle (oracle/, the CPU restatement of
+the reference decoder) on a bounded sample of the same workload on this host -- the oracle is used
+only there.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (alist, design sigma, max_iter, qbits_cha, qbits_msg, default batch, extra design kwargs, known rank)
+    "dvbs2": ("rate0.50_irreg_dvbs2_N64800", 0.88, 50, 4, 4, 4096, dict(allow_degree_one=True), 32400),
+    "twin": ("rate0.50_dv02-08_dc07-08_lut_q4_N64800", 0.88, 50, 4, 4, 4096, {}, 32400),
+    "c2": ("rate0.50_dv03_dc06_N10000", 0.84, 50, 4, 4, 4096, {}, 5000),
+    "c1": ("rate0.50_dv02-17_dc08-09_lut_q4_N500", 0.88, 50, 4, 4, 16384, {}, 250),
+}
+
+
+def make_labels(cd, B, snr_db, seed):
+    """All-zero codeword over BPSK/AWGN (src/LDPC_BER_Sim.cpp:248-278) quantised with the designed
+    boundaries; generated on the host once, outside the timed region."""
+    rng = np.random.default_rng(seed)
+    N0 = 10 ** (-snr_db / 10) / cd.rate
+    qc, qm = cd.qb_cha, cd.qb_msg
+    cha = np.empty((B, cd.nvar), np.uint8)
+    msg = np.empty((B, cd.nvar), np.uint8)
+    step = max(1, (1 << 24) // cd.nvar)
+    for b0 in range(0, B, step):
+        x = 1.0 + rng.normal(0.0, np.sqrt(N0 / 2), (min(step, B - b0), cd.nvar))
+        llr = 4 * x / N0
+        # quant_nonlin: number of boundaries strictly below the value (src/common.cpp:120-129)
+        cha[b0:b0 + len(llr)] = np.searchsorted(qc, llr, side="left").astype(np.uint8)
+        msg[b0:b0 + len(llr)] = np.searchsorted(qm, llr, side="left").astype(np.uint8)
+    return cha, msg
+
+
+def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=15.0):
+    """The oracle (single-threaded restatement of the reference's per-output queue/recursion decoder)
+    on a bounded sample of the same labels.  Tables are handed over as the reference's tree text."""
+    from oracle import oracle as orc
+    code = orc.Code(ROOT / "data" / "codes" / f"{cd.alist}.alist")
+    oc = orc.Codec(code, skip_rank=True)
+    nq = np.full(max_iter, cd.nq_msg, np.int32)
+    oc.set_trees_txt(cd.var_trees_txt, "", max_iter, np.zeros(max_iter, np.uint8), cd.nq_cha, nq, True)
+    oc.set_exit_conditions(max_iter, psc, psc)
+    t0 = time.perf_counter()
+    oc.lut_decode_batch(cha[:1], msg[:1])
+    t1 = time.perf_counter() - t0
+    n = int(max(2, min(len(cha), budget_s / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    bits, iters = oc.lut_decode_batch(cha[:n], msg[:n])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "codewords/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames of the same labels, oracle faithful mode (per-output queue copy + recursive tree walk), "
+                      f"{dt:.1f} s on this host"}, bits, iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="dvbs2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step")
+    ap.add_argument("--mode", default="fixed", choices=["fixed", "shipped"],
+                    help="fixed: parity_check_iter=false (all iterations); shipped: syndrome checks + early termination")
+    ap.add_argument("--snr", type=float, default=None, help="Eb/N0 in dB of the synthetic frames")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lut_ldpc_amd as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or L.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    alist, sigma, max_iter, qc, qm, B_default, extra, known_rank = WORKLOADS[args.workload]
+    B = args.batch or B_default
+    psc = args.mode == "shipped"
+    snr = args.snr if args.snr is not None else (-10 * np.log10(2 * 0.5 * sigma * sigma) if not psc else 1.5)
+
+    # ---- set-up (untimed): alist -> design LUTs by density evolution -> HIP decoder --------------
+    cd = L.Codec(ROOT / "data" / "codes" / f"{alist}.alist", known_rank=known_rank, device=local)
+    cd.alist, cd.nq_cha, cd.nq_msg = alist, 1 << qc, 1 << qm
+    cd.design_luts(sigma2=sigma * sigma, max_iters=max_iter, nq_cha=1 << qc, nq_msg=1 << qm, **extra)
+    cd.set_exit_conditions(max_iter, psc, psc)
+    dec = cd.decoder()
+    N, E, I = cd.nvar, cd.nedges, max_iter
+
+    cha_h, msg_h = make_labels(cd, B, snr, seed=1234 + rank)
+    cha = torch.from_numpy(cha_h).cuda()
+    msg = torch.from_numpy(msg_h).cuda()
+    out_bits = torch.empty((B, N), dtype=torch.uint8, device="cuda")
+    out_iters = torch.empty(B, dtype=torch.int32, device="cuda")
+    counters = torch.zeros(5, dtype=torch.int64, device="cuda")   # frames, data bits, frame errs, bit errs, uncoded errs
+
+    def step(sync):
+        dec.lut_decode_batch_device(cha.data_ptr(), msg.data_ptr(), B, out_bits.data_ptr(), out_iters.data_ptr(), sync=sync)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(True)
+    dec.set_profiling(True)
+    dec.reset_profile()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k == args.steps - 1)
+    # BER/FER counters of the last step, summed over ranks (src/LDPC_BER_Sim.hpp:80-85 payload)
+    K_info = N - cd.rank
+    info = out_bits[:, :K_info]
+    counters[0] = B
+    counters[1] = B * K_info
+    counters[2] = (info.any(dim=1)).sum()
+    counters[3] = info.sum(dtype=torch.int64)
+    counters[4] = (cha < (1 << qc) // 2).sum(dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(counters)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    prof = dec.profile()
+    dec.set_profiling(False)
+
+    frames = B * args.steps * world
+    value = frames / dt
+    vn, cn = prof["vn_pass"], prof["cn_pass"]
+    vn_ms = vn["ms"] / max(vn["launches"], 1)
+    cn_ms = cn["ms"] / max(cn["launches"], 1)
+    b_msg = 1                                           # bytes per stored edge message (uint8)
+    vn_bytes = (2 * E * b_msg + N) * B                  # read E, write E, read cha (N)
+    cn_bytes = 2 * E * b_msg * B
+    if psc:
+        vn_bytes += N * B                               # hard-decision rows written for the syndrome test
+    it_exec = float(out_iters.abs().float().mean().item())
+    result = {
+        "metric": "decoded codewords/sec, DVB-S2 N=64800 4-bit LUT 50-iter" if args.workload == "dvbs2" else "decoded codewords/sec",
+        "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "coded_bits_per_s": value * N,
+        "config": {"workload": f"{alist}, {qc}-bit channel / {qm}-bit messages, {max_iter} iterations, min-LUT, "
+                               f"{'fixed work (parity_check_iter=false)' if not psc else 'as shipped (syndrome checks, early termination)'}",
+                   "frames_per_gpu_per_step": B, "N": N, "E": E, "design_sigma": sigma, "EbN0_dB": round(float(snr), 3),
+                   "mean_iterations_executed": it_exec, "parallelism": f"frames sharded over {world} GPU(s), counters all-reduced",
+                   "kernels": dec.describe()},
+        "roofline": {"bound": "hbm", "kernel": "vn_pass", "achieved": vn_bytes / (vn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": vn_bytes / (vn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": vn_bytes, "avg_launch_ms": vn_ms, "launches": vn["launches"]},
+        "roofline_cn_pass": {"bound": "hbm", "achieved": cn_bytes / (cn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": cn_bytes / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": cn_bytes,
+                             "avg_launch_ms": cn_ms, "launches": cn["launches"]},
+        "roofline_whole_decode": {"algorithmic_bytes_per_frame": 4 * I * E * b_msg + (I + 2) * N + N / 8,
+                                  "achieved_GBps": (4 * I * E * b_msg + (I + 2) * N + N / 8) * value / world / 1e9},
+        "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+        "counters": {"frames": int(counters[0]), "data_bits": int(counters[1]), "frame_errors": int(counters[2]),
+                     "data_bit_errors": int(counters[3]), "uncoded_bit_errors": int(counters[4])},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, ob, oi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
+        n = len(oi)
+        same = bool((ob == out_bits[:n].cpu().numpy()).all() and (oi == out_iters[:n].cpu().numpy()).all())
+        base["gpu_matches_oracle_on_sample"] = same
+        result["cpu_baseline"] = base
+        if not same:
+            raise SystemExit("GPU output differs from the oracle on the cpu_baseline sample")
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
