@@ -111,7 +111,7 @@ class Codec:
         d = Decoder.__new__(Decoder)
         d._h = C.c_void_p(h)
         d.nvar, d.nchk, d.max_iters, d.device = self.nvar, self.nchk, self.max_iters, 0
-        d.close = lambda: None      # owned by the codec
+        d._owned = False            # the codec owns (and destroys) the handle
         d._owner = self
         return d
 

@@ -32,6 +32,7 @@ class Decoder:
         nq, ru = _i32(nq_msg), np.ascontiguousarray(reuse_vec, np.uint8)
         assert len(nq) == max_iters and len(ru) == max_iters
         self._h = C.c_void_p()
+        self._owned = True
         check(lib.lutldpc_decoder_create(self.nvar, self.nchk, _p(dv, C.c_int32), _p(dc, C.c_int32), _p(cn, C.c_int32),
                                          int(nq_cha), _p(nq, C.c_int32), _p(ru, C.c_uint8), self.max_iters, int(bool(min_lut)),
                                          var_trees_txt.encode(), (chk_trees_txt or "").encode(), int(device),
@@ -39,11 +40,12 @@ class Decoder:
         self.device = device
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owned", False):
             lib.lutldpc_decoder_destroy(self._h)
-            self._h = None
+        self._h = None
 
-    __del__ = close
+    def __del__(self):
+        self.close()
 
     def set_exit_conditions(self, max_iters, psc=True, pisc=False):
         check(lib.lutldpc_decoder_set_exit_conditions(self._h, int(max_iters), int(psc), int(pisc)))
