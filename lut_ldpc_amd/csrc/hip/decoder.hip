@@ -83,6 +83,7 @@ struct lutldpc_decoder {
     std::vector<uint8_t> all_tables;
     std::vector<PassPlan> var_plan, chk_plan, dec_plan;   // per tree set
     PassPlan cn_minsum_plan;
+    std::vector<std::vector<FastClassPlan>> var_fast, dec_fast;   // [set][class]
     // ---- device
     int device = -1;
     hipStream_t stream = nullptr;
@@ -99,6 +100,7 @@ struct lutldpc_decoder {
     DevBuf<int32_t> d_map;
     // ---- tuning
     int nodes_per_block = 16;
+    int nodes_per_wave = 8;     // specialised kernels
     int use_fast = 1;
     // ---- profiling
     bool profiling = false;
@@ -209,9 +211,11 @@ int compile_all(lutldpc_decoder *d) {
     }
     d->all_ops.clear(); d->all_tables.clear();
     auto add_set = [&](const std::vector<Tree> &trees, const std::vector<NodeClass> &cls, int kind,
-                       std::vector<Program> &progs, PassPlan &plan) -> int {
+                       std::vector<Program> &progs, PassPlan &plan, std::vector<FastClassPlan> *fast) -> int {
         progs.resize(cls.size());
+        if (fast) fast->assign(cls.size(), FastClassPlan());
         std::vector<size_t> op_off(cls.size()), tab_off(cls.size());
+        int node_off = 0;
         for (size_t i = 0; i < cls.size(); i++) {
             if (cls[i].tree_class >= (int)trees.size()) return fail(LUTLDPC_ERR_ARG, "tree set is missing a degree class");
             const Tree &t = trees[(size_t)cls[i].tree_class];
@@ -221,20 +225,27 @@ int compile_all(lutldpc_decoder *d) {
             op_off[i] = d->all_ops.size(); tab_off[i] = d->all_tables.size();
             d->all_ops.insert(d->all_ops.end(), progs[i].ops.begin(), progs[i].ops.end());
             d->all_tables.insert(d->all_tables.end(), progs[i].tables.begin(), progs[i].tables.end());
+            if (fast) {
+                std::map<const TreeNode *, std::pair<uint32_t, uint32_t>> tab_of;
+                for (auto &nt : progs[i].node_tabs) tab_of[nt.first] = {(uint32_t)tab_off[i] + nt.second[0], nt.second[1]};
+                (*fast)[i] = plan_fast_vn(t, kind, cls[i].deg, tab_of, node_off, (int)cls[i].nodes.size());
+            }
+            node_off += (int)cls[i].nodes.size();
         }
         return build_plan(d, cls, &progs, &op_off, &tab_off, plan);
     };
     size_t ns = (size_t)n_sets;
     d->var_prog.assign(ns, {}); d->dec_prog.assign(ns, {}); d->chk_prog.assign(ns, {});
     d->var_plan.assign(ns, {}); d->dec_plan.assign(ns, {}); d->chk_plan.assign(ns, {});
+    d->var_fast.assign(ns, {}); d->dec_fast.assign(ns, {});
     for (size_t s = 0; s < ns; s++) {
         // a set is either message-update trees or (the last one) decision trees
         int type = d->var_trees[s].empty() ? TT_VAR : d->var_trees[s][0].type;
         int rc;
-        if (type == TT_DEC) rc = add_set(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog[s], d->dec_plan[s]);
-        else rc = add_set(d->var_trees[s], d->vclass, TT_VAR, d->var_prog[s], d->var_plan[s]);
+        if (type == TT_DEC) rc = add_set(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog[s], d->dec_plan[s], &d->dec_fast[s]);
+        else rc = add_set(d->var_trees[s], d->vclass, TT_VAR, d->var_prog[s], d->var_plan[s], &d->var_fast[s]);
         if (rc) return rc;
-        if (!d->min_lut) { rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s]); if (rc) return rc; }
+        if (!d->min_lut) { rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s], nullptr); if (rc) return rc; }
     }
     if (d->min_lut) { int rc = build_plan(d, d->cclass, nullptr, nullptr, nullptr, d->cn_minsum_plan); if (rc) return rc; }
     return LUTLDPC_OK;
@@ -298,32 +309,54 @@ int launch_syndrome(lutldpc_decoder *d, int G) {
     return LUTLDPC_OK;
 }
 
+// keep only the classes flagged in `keep` (the others were handled by specialised kernels)
+PassParams filter_params(const PassParams &P, const std::vector<char> &keep) {
+    PassParams Q = P;
+    Q.n_seg = 0;
+    int blk = 0;
+    for (int i = 0; i < P.n_seg; i++) {
+        if (!keep[(size_t)i]) continue;
+        PassSeg S = P.seg[i];
+        S.block_begin = blk;
+        blk += (S.n_nodes + P.nodes_per_block - 1) / P.nodes_per_block;
+        Q.seg[Q.n_seg++] = S;
+    }
+    Q.blocks_per_group = blk;
+    return Q;
+}
+
 template <int KIND>
-int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, int G, int nz, int check, int write_hard, int kind_id) {
+int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPlan> *fast, int G, int nz, int check, int write_hard, int kind_id) {
     if (!plan.valid) return fail(LUTLDPC_ERR_STATE, "pass plan missing for this tree set");
     Timed t(d, kind_id);
     PassParams P = plan.P;
     P.G = G; P.nz = nz; P.check = check; P.write_hard = write_hard;
-    // specialised kernels take the classes they know; the interpreter handles the rest
-    if (d->use_fast && KIND != TT_CHK) {
-        int rc = launch_fast_tree_pass<KIND>(d->stream, P, plan.lds_tab, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
-                                             reinterpret_cast<const uint32_t *>(d->d_state.p),
-                                             reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_ops.p, d->d_tables.p,
-                                             d->d_vn_list.p, d->d_vn_ptr.p);
-        if (rc < 0) return fail(LUTLDPC_ERR_HIP, "fast pass launch failed");
-        if (rc == 1) { LAUNCH_CHECK(); return LUTLDPC_OK; }
+    std::vector<char> keep((size_t)P.n_seg, 1);
+    bool any = false;
+    // specialised kernels take the classes they know, one launch per degree class
+    if (d->use_fast && fast && KIND != TT_CHK)
+        for (int i = 0; i < P.n_seg; i++) {
+            if (!(*fast)[(size_t)i].ok) continue;
+            if (launch_vn_fast<KIND>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->nodes_per_wave, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
+                                     reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
+                                     d->d_vn_list.p, d->d_vn_ptr.p, d->E, d->nvar))
+                keep[(size_t)i] = 0;
+        }
+    for (char k : keep) any = any || k;
+    if (any) {
+        P = filter_params(P, keep);
+        dim3 grid((unsigned)(P.blocks_per_group * G)), block(64);
+        const int32_t *list = KIND == TT_CHK ? d->d_cn_list.p : d->d_vn_list.p;
+        const int32_t *ptr = KIND == TT_CHK ? d->d_cn_ptr.p : d->d_vn_ptr.p;
+        if (plan.lds_tab)
+            hipLaunchKernelGGL((tree_pass_kernel<KIND, true>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+                               d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
+        else
+            hipLaunchKernelGGL((tree_pass_kernel<KIND, false>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+                               d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
     }
-    dim3 grid((unsigned)(P.blocks_per_group * G)), block(64);
-    const int32_t *list = KIND == TT_CHK ? d->d_cn_list.p : d->d_vn_list.p;
-    const int32_t *ptr = KIND == TT_CHK ? d->d_cn_ptr.p : d->d_vn_ptr.p;
-    if (plan.lds_tab)
-        hipLaunchKernelGGL((tree_pass_kernel<KIND, true>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
-                           d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                           d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
-    else
-        hipLaunchKernelGGL((tree_pass_kernel<KIND, false>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
-                           d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                           d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -332,15 +365,21 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     Timed t(d, LUTLDPC_K_CN_PASS);
     PassParams P = d->cn_minsum_plan.P;
     P.G = G; P.nz = nz; P.check = check;
-    if (d->use_fast) {
-        int rc = launch_fast_cn_minsum(d->stream, P, d->d_msgs.p, reinterpret_cast<const uint32_t *>(d->d_state.p),
-                                       reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
-        if (rc < 0) return fail(LUTLDPC_ERR_HIP, "fast check pass launch failed");
-        if (rc == 1) { LAUNCH_CHECK(); return LUTLDPC_OK; }
+    std::vector<char> keep((size_t)P.n_seg, 1);
+    bool any = false;
+    if (d->use_fast)
+        for (int i = 0; i < P.n_seg; i++)
+            if (launch_cn_fast(d->stream, P.seg[i].deg, P.seg[i].n_nodes, P.seg[i].node_off, G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
+                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_list.p,
+                               d->d_cn_ptr.p, d->d_cn_idx.p))
+                keep[(size_t)i] = 0;
+    for (char k : keep) any = any || k;
+    if (any) {
+        P = filter_params(P, keep);
+        hipLaunchKernelGGL(cn_minsum_generic_kernel, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
+                           reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                           d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
     }
-    hipLaunchKernelGGL(cn_minsum_generic_kernel, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
-                       reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                       d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -386,17 +425,17 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
         const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
         const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
         if (d->min_lut) rc = launch_cn_minsum(d, G, nz_in, chk_check);
-        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
+        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
         if (rc) return rc;
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
         if (ii != I - 1) {
             const int nz_out = d->Nq_Msg[(size_t)(ii + 1)] / 2;
-            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
+            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
             if (rc) return rc;
         }
     }
     // :340-349
-    if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
+    if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
     if ((rc = launch_syndrome(d, G))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
     {
@@ -412,13 +451,19 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
 void make_describe(lutldpc_decoder *d) {
     std::ostringstream o;
     o << "{\"tile_frames\":" << kTileFrames << ",\"message_bytes\":1,\"vector_bytes_per_lane\":4"
-      << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"use_fast\":" << d->use_fast
+      << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"nodes_per_wave\":" << d->nodes_per_wave << ",\"use_fast\":" << d->use_fast
       << ",\"vn_classes\":[";
-    for (size_t i = 0; i < d->vclass.size(); i++) o << (i ? "," : "") << "{\"deg\":" << d->vclass[i].deg << ",\"nodes\":" << d->vclass[i].nodes.size()
-        << ",\"kernel\":\"" << fast_vn_kernel_name(d->use_fast, d->vclass[i].deg, d->var_prog.empty() || d->var_prog[0].empty() ? nullptr : &d->var_prog[0][i]) << "\"}";
+    for (size_t i = 0; i < d->vclass.size(); i++) {
+        const bool f = d->use_fast && !d->var_fast.empty() && i < d->var_fast[0].size() && d->var_fast[0][i].ok && d->vclass[i].deg <= kFastMaxDeg;
+        o << (i ? "," : "") << "{\"deg\":" << d->vclass[i].deg << ",\"nodes\":" << d->vclass[i].nodes.size() << ",\"kernel\":\""
+          << (f ? "vn_balanced_fast_kernel" : "tree_pass_kernel<VAR>") << "\"}";
+    }
     o << "],\"cn_classes\":[";
-    for (size_t i = 0; i < d->cclass.size(); i++) o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size()
-        << ",\"kernel\":\"" << (d->min_lut ? fast_cn_kernel_name(d->use_fast, d->cclass[i].deg) : "tree_pass_kernel<CHK>") << "\"}";
+    for (size_t i = 0; i < d->cclass.size(); i++) {
+        const bool f = d->use_fast && d->min_lut && d->cclass[i].deg <= 32 && is_pow2(d->Nq_Msg[0] / 2);
+        o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size() << ",\"kernel\":\""
+          << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel") : "tree_pass_kernel<CHK>") << "\"}";
+    }
     o << "]}";
     d->describe = o.str();
 }
@@ -489,6 +534,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     }
     if (const char *e = getenv("LUTLDPC_NODES_PER_BLOCK")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_block = v; }
     if (const char *e = getenv("LUTLDPC_USE_FAST")) d->use_fast = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave = v; }
     int rc = compile_all(d.get());
     if (rc) return rc;
     d->device = device;

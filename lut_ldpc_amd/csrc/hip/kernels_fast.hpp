@@ -1,25 +1,432 @@
 // kernels_fast.hpp -- specialised gfx950 kernels for the shapes ber_sim actually produces:
-// min-sum check nodes of small degree and balanced binary variable/decision trees.
-// A launcher returns 1 when it handled the whole pass, 0 when the pass must go to the generic
-// kernels, <0 on a launch error.
+//   * min-sum check nodes (src/LDPC_Code_LUT.cpp:355-402) with the check's rows held in
+//     registers and byte-parallel (SWAR) arithmetic on the four frames packed in each dword;
+//   * variable / decision nodes whose tree is the balanced binary tree of
+//     LUT_Tree_Node::gen_bin_balanced_tree (src/LUT_Tree.cpp:200-237) -- the only shape
+//     ber_sim designs in its auto modes (src/LDPC_BER_Sim.cpp:487-489) -- evaluated as
+//     straight-line code with every shared sub-expression computed once.
+// Everything else (file trees, CHKTREE checks, odd alphabets) goes to kernels_generic.hpp.
+//
+// Roofline: both passes are HBM-bound streaming of 256-byte rows (measured ceiling for this
+// in-place gather/scatter pattern on MI355X: ~5.0-5.2 TB/s, tests/microbench/rows.hip).
+// Algorithmic bytes per launch: check pass 2*E*B, variable pass (2*E + N)*B (+N*B when the
+// hard decisions are written for the early-termination test).
 #pragma once
 #include "kernels_common.hpp"
 #include "lut_program.hpp"
 
+#include <utility>
+
 namespace lutldpc {
 
+constexpr int kFastMaxTables = 32;     // LUT nodes of one balanced tree (degree <= 33)
+constexpr int kFastTableStride = 256;  // bytes per table slot in LDS
+
+struct FastParams {
+    int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
+    int32_t G, E, N;
+    int32_t nz;            // sign threshold (see PassParams)
+    int32_t shift_msg;     // log2 of the message alphabet feeding the tables (label = a | b << shift)
+    int32_t check, write_hard;
+    int32_t deg;
+    int32_t n_tables;
+    int32_t tab_off[kFastMaxTables];    // byte offsets into the table blob, canonical node order
+    int32_t tab_len[kFastMaxTables];
+    int32_t tab_shift[kFastMaxTables];  // log2 alphabet of each table's first child
+};
+
+// ------------------------------------------------------------------------------------------
+// SWAR byte minimum for values < 128
+__device__ __forceinline__ uint32_t swar_min(uint32_t a, uint32_t b) {
+    const uint32_t d = (a | 0x80808080u) - b;                    // bit7 of each byte: a >= b
+    const uint32_t m = ((d >> 7) & 0x01010101u) * 0xFFu;
+    return bfi(m, b, a);
+}
+
+// Min-sum check pass.  DMAX: register budget (rows kept per check); the true degree is the
+// wave-uniform runtime value P.deg <= DMAX.  QBITS: log2(Nq_Msg) (Nq a power of two).
+// One wave = one 256-frame row segment; UNR checks are in flight per wave.
+template <int DMAX, int UNR>
+__global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
+    FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+    const int32_t *__restrict__ node_list, const int32_t *__restrict__ cn_ptr, const int32_t *__restrict__ cn_idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = wave / P.waves_per_group;
+    if (g >= P.G) return;
+    const int chunk = wave - g * P.waves_per_group;
+    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
+    if (wave_all_zero(amask)) return;
+    uint8_t *base = msgs + (size_t)g * (size_t)P.E * kTileFrames + lane * 4;
+    const int first = chunk * P.nodes_per_wave;
+    int last = first + P.nodes_per_wave;
+    if (last > P.n_nodes) last = P.n_nodes;
+    const int deg = P.deg;
+    const uint32_t nzm1 = (uint32_t)(P.nz - 1);
+    const uint32_t magmask = nzm1 * 0x01010101u;
+    const int sbit = __builtin_ctz((unsigned)P.nz);              // sign bit position (label >= nz <=> bit set)
+    uint32_t fail = 0;
+
+    for (int i = first; i < last; i += UNR) {
+        uint32_t x[UNR][DMAX];
+        int e[UNR][DMAX];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int ii = (i + u < last) ? i + u : last - 1;
+            const int c = __builtin_amdgcn_readfirstlane(node_list[P.node_off + ii]);
+            const int p0 = __builtin_amdgcn_readfirstlane(cn_ptr[c]);
+#pragma unroll
+            for (int k = 0; k < DMAX; k++)
+                if (k < deg) {
+                    e[u][k] = __builtin_amdgcn_readfirstlane(cn_idx[p0 + k]);
+                    x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kTileFrames);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (i + u >= last) break;
+            uint32_t min1 = (uint32_t)P.nz * 0x01010101u, min2 = min1, sp = 0;
+            uint32_t pk[DMAX];                                    // magnitude | negative << 7
+#pragma unroll
+            for (int k = 0; k < DMAX; k++)
+                if (k < deg) {
+                    const uint32_t ng = (~x[u][k] >> sbit) & 0x01010101u;       // label < nz
+                    const uint32_t mag = (x[u][k] ^ (ng * nzm1)) & magmask;     // nz-1-label | label-nz
+                    sp ^= ng;
+                    const uint32_t lo = swar_min(mag, min1);
+                    const uint32_t hi = mag ^ min1 ^ lo;
+                    min2 = swar_min(min2, hi);
+                    min1 = lo;
+                    pk[k] = mag | (ng << 7);
+                }
+            if (P.check) fail |= sp;
+#pragma unroll
+            for (int k = 0; k < DMAX; k++)
+                if (k < deg) {
+                    const uint32_t mag = pk[k] & 0x7F7F7F7Fu, ng = (pk[k] >> 7) & 0x01010101u;
+                    const uint32_t eq = swar_zero_mask(mag ^ min1);            // this edge holds the minimum
+                    const uint32_t m = bfi(eq, min2, min1);
+                    const uint32_t so = sp ^ ng;                                // sign of the extrinsic product
+                    // negative: nz-1-m ; positive: nz+m
+                    const uint32_t r = (m ^ (so * nzm1)) | ((so ^ 0x01010101u) << sbit);
+                    *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kTileFrames) = bfi(amask, r, x[u][k]);
+                }
+        }
+    }
+    if (P.check) {
+        fail &= amask;
+        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Balanced binary trees at compile time.
+// N message leaves are paired front-to-back through a FIFO (src/LUT_Tree.cpp:203-235); leaves are
+// then renumbered by depth-first position, because a leaf at position p consumes queue element p
+// (src/LUT_Tree.cpp:402-407).  Internal nodes are numbered in creation order (children first).
+template <int N>
+struct BalShape {
+    static constexpr int NI = N > 1 ? N - 1 : 0;      // internal (LUT) nodes below the root
+    int left[NI > 0 ? NI : 1] = {};                   // child ids: < N leaf (creation id), >= N internal
+    int right[NI > 0 ? NI : 1] = {};
+    int size[2 * N] = {};                              // leaves below each node
+    int first[2 * N] = {};                             // DFS position of its first leaf
+    int off[NI > 0 ? NI : 1] = {};                    // offset of its variants in the value array
+    int top = 0;                                       // id of the subtree root
+    int total = 0;                                     // sum over internal nodes of (size + 1)
+};
+
+template <int N>
+constexpr BalShape<N> make_bal_shape() {
+    BalShape<N> S{};
+    int fifo[2 * N + 2] = {};
+    int head = 0, tail = 0, next = N;
+    for (int l = 0; l < N; l++) { fifo[tail++] = l; S.size[l] = 1; }
+    while (tail - head > 1) {
+        const int a = fifo[head++], b = fifo[head++];
+        S.left[next - N] = a; S.right[next - N] = b;
+        S.size[next] = S.size[a] + S.size[b];
+        fifo[tail++] = next++;
+    }
+    S.top = fifo[head];
+    // DFS positions (explicit stack)
+    int stack[2 * N + 2] = {};
+    int sp = 0, pos = 0;
+    stack[sp++] = S.top;
+    // pre-order walk assigning `first`; children pushed right then left
+    while (sp > 0) {
+        const int nd = stack[--sp];
+        S.first[nd] = pos;
+        if (nd < N) { pos += 1; continue; }
+        // the first leaf of an internal node is the first leaf of its left child: handled when
+        // the left child is popped next (pos unchanged until a leaf is met)
+        stack[sp++] = S.right[nd - N];
+        stack[sp++] = S.left[nd - N];
+    }
+    int total = 0;
+    for (int j = 0; j < BalShape<N>::NI; j++) { S.off[j] = total; total += S.size[N + j] + 1; }
+    S.total = total;
+    return S;
+}
+
+template <int N>
+struct Bal {
+    static constexpr BalShape<N> S = make_bal_shape<N>();
+};
+
+// one look-up for the four packed frames: label = a | b << sh, table slot `t` in LDS
+__device__ __forceinline__ uint32_t lut4(const uint8_t *lds_tab, int t, uint32_t a, uint32_t b, int sh) {
+    const uint32_t L = a | (b << sh);
+    const uint8_t *tb = lds_tab + t * kFastTableStride;
+    const uint32_t r0 = tb[L & 0xFFu], r1 = tb[(L >> 8) & 0xFFu], r2 = tb[(L >> 16) & 0xFFu], r3 = tb[L >> 24];
+    return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+}
+
+// value of child `c` of the balanced tree in variant kc (the first kc leaves of the subtree read
+// the queue unshifted, the others read one element further: the removed message lies before them)
+template <int N, int C, int KC>
+__device__ __forceinline__ uint32_t bal_child(const uint32_t *in, const uint32_t *v) {
+    constexpr auto &S = Bal<N>::S;
+    if constexpr (C < N) return in[S.first[C] + (KC ? 0 : 1)];
+    else return v[S.off[C - N] + KC];
+}
+
+template <int N, int J, int K>
+__device__ __forceinline__ void bal_node_variant(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh) {
+    constexpr auto &S = Bal<N>::S;
+    constexpr int L = S.left[J], R = S.right[J], sl = S.size[L];
+    constexpr int kl = K < sl ? K : sl, kr = K > sl ? K - sl : 0;
+    v[S.off[J] + K] = lut4(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
+}
+
+template <int N, int J, int... Ks>
+__device__ __forceinline__ void bal_node_all(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Ks...>) {
+    (bal_node_variant<N, J, Ks>(in, v, tab, sh), ...);
+}
+// VAR: all variants of every node; DEC (ALL = false): only the unshifted variant K = size
+template <int N, bool ALL, int... Js>
+__device__ __forceinline__ void bal_all_nodes(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Js...>) {
+    if constexpr (ALL) (bal_node_all<N, Js>(in, v, tab, sh, std::make_integer_sequence<int, Bal<N>::S.size[N + Js] + 1>{}), ...);
+    else (bal_node_variant<N, Js, Bal<N>::S.size[N + Js]>(in, v, tab, sh), ...);
+}
+
+// Variable-node (KIND = TT_VAR) / decision (TT_DEC) pass for degree-DV nodes with balanced trees.
+// Tables: slots 0..NI-1 = internal nodes in creation order, slot NI = root.
+// DV == 1 (VAR only): ROOT(CHA), the build's degree-1 extension.
+template <int DV, int KIND, bool CHECK>
+__global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
+    FastParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
+    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
+    const int32_t *__restrict__ node_list, const int32_t *__restrict__ vn_ptr)
+{
+    constexpr int N = (KIND == TT_DEC) ? DV : DV - 1;          // message leaves
+    constexpr int NI = N > 1 ? N - 1 : 0;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[(NI + 1) * kFastTableStride];
+    // stage the class tables (canonical order, fixed 256-byte slots)
+    for (int t = 0; t <= NI; t++) {
+        const uint8_t *src = tables + P.tab_off[t];
+        for (int i = threadIdx.x; i < P.tab_len[t]; i += 256) lds_tab[t * kFastTableStride + i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = wave / P.waves_per_group;
+    if (g >= P.G) return;
+    const int chunk = wave - g * P.waves_per_group;
+    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
+    if (wave_all_zero(amask)) return;
+    uint8_t *mbase = msgs + (size_t)g * (size_t)P.E * kTileFrames + lane * 4;
+    const uint8_t *cbase = cha + (size_t)g * (size_t)P.N * kTileFrames + lane * 4;
+    uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kTileFrames + lane * 4;
+    const int first = chunk * P.nodes_per_wave;
+    int last = first + P.nodes_per_wave;
+    if (last > P.n_nodes) last = P.n_nodes;
+    const int sh = P.shift_msg;
+    uint32_t fail = 0;
+
+    for (int i = first; i < last; i++) {
+        const int v = __builtin_amdgcn_readfirstlane(node_list[P.node_off + i]);
+        const int e0 = __builtin_amdgcn_readfirstlane(vn_ptr[v]);
+        uint32_t in[DV + 1];
+#pragma unroll
+        for (int k = 0; k < DV; k++) in[k] = *reinterpret_cast<const uint32_t *>(mbase + (size_t)(e0 + k) * kTileFrames);
+        const uint32_t ch = *reinterpret_cast<const uint32_t *>(cbase + (size_t)v * kTileFrames);
+        in[DV] = ch;
+        uint32_t val[(N > 1 ? Bal<(N > 1 ? N : 2)>::S.total : 1)];
+        if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
+        if constexpr (KIND == TT_DEC) {
+            uint32_t top;
+            if constexpr (N > 1) top = val[Bal<N>::S.off[Bal<N>::S.top - N] + N];
+            else top = in[0];
+            const uint32_t r = lut4(lds_tab, NI, top, ch, P.tab_shift[NI]);
+            const uint32_t bit = swar_lt(r, 1u);                        // src/LDPC_Code_LUT.cpp:342
+            uint32_t *hp = reinterpret_cast<uint32_t *>(hbase + (size_t)v * kTileFrames);
+            if (amask == 0xFFFFFFFFu) *hp = bit;
+            else if (amask) *hp = bfi(amask, bit, *hp);
+        } else {
+            uint32_t neg_ref = 0;
+#pragma unroll
+            for (int o = 0; o < DV; o++) {
+                uint32_t r;
+                if constexpr (N == 0) {
+                    // degree 1: the only leaf is the channel label
+                    const uint32_t L = ch;
+                    const uint8_t *tb = lds_tab;
+                    r = (uint32_t)tb[L & 0xFFu] | ((uint32_t)tb[(L >> 8) & 0xFFu] << 8) | ((uint32_t)tb[(L >> 16) & 0xFFu] << 16) | ((uint32_t)tb[L >> 24] << 24);
+                } else {
+                    uint32_t top;
+                    if constexpr (N > 1) top = val[Bal<(N > 1 ? N : 2)>::S.off[Bal<(N > 1 ? N : 2)>::S.top - N] + o];
+                    else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
+                    r = lut4(lds_tab, NI, top, ch, P.tab_shift[NI]);
+                }
+                *reinterpret_cast<uint32_t *>(mbase + (size_t)(e0 + o) * kTileFrames) = bfi(amask, r, in[o]);
+                if (CHECK) {
+                    const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
+                    if (o == 0) neg_ref = ng; else fail |= ng ^ neg_ref;
+                }
+            }
+            if (CHECK && P.write_hard) {
+                uint32_t *hp = reinterpret_cast<uint32_t *>(hbase + (size_t)v * kTileFrames);
+                if (amask == 0xFFFFFFFFu) *hp = neg_ref;
+                else if (amask) *hp = bfi(amask, neg_ref, *hp);
+            }
+        }
+    }
+    if (KIND == TT_VAR && CHECK) {
+        fail &= amask;
+        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: does a runtime tree have the balanced shape for degree d?  If so return its LUT
+// nodes in canonical order (internal nodes in creation order, then the root).
+inline bool match_balanced(const Tree &t, int kind, int d, std::vector<const TreeNode *> &canon) {
+    canon.clear();
+    const int n = (kind == TT_DEC) ? d : d - 1;
+    const TreeNode *root = t.root.get();
+    if (!root || root->type != NT_ROOT) return false;
+    if (n == 0) {      // degree-1 extension: ROOT(CHA)
+        if (root->child.size() != 1 || root->child[0]->type != NT_CHA) return false;
+        canon.push_back(root);
+        return true;
+    }
+    if (root->child.size() != 2 || root->child[1]->type != NT_CHA || !root->child[1]->child.empty()) return false;
+    // rebuild the canonical shape at run time (same FIFO pairing as make_bal_shape)
+    std::vector<int> left, right, fifo;
+    for (int l = 0; l < n; l++) fifo.push_back(l);
+    size_t head = 0;
+    int next = n;
+    while (fifo.size() - head > 1) {
+        left.push_back(fifo[head]); right.push_back(fifo[head + 1]);
+        head += 2;
+        fifo.push_back(next++);
+    }
+    const int top = fifo[head];
+    std::vector<const TreeNode *> node_of((size_t)(2 * n), nullptr);
+    // simultaneous walk
+    struct Item { int id; const TreeNode *tn; };
+    std::vector<Item> stack{{top, root->child[0].get()}};
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.id < n) {
+            if (it.tn->type != NT_MSG || !it.tn->child.empty()) return false;
+            continue;
+        }
+        if (it.tn->type != NT_IM || it.tn->child.size() != 2) return false;
+        node_of[(size_t)it.id] = it.tn;
+        stack.push_back({right[(size_t)(it.id - n)], it.tn->child[1].get()});
+        stack.push_back({left[(size_t)(it.id - n)], it.tn->child[0].get()});
+    }
+    for (int j = n; j < 2 * n - 1; j++) { if (!node_of[(size_t)j]) return false; canon.push_back(node_of[(size_t)j]); }
+    canon.push_back(root);
+    return true;
+}
+
+inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// Per-class plan of a fast variable/decision pass (filled at create time)
+struct FastClassPlan {
+    bool ok = false;
+    FastParams P{};
+};
+
+// tab_of: LUT node -> (offset in the global blob, length)
+inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map<const TreeNode *, std::pair<uint32_t, uint32_t>> &tab_of, int node_off, int n_nodes) {
+    FastClassPlan fp;
+    std::vector<const TreeNode *> canon;
+    if (d < 1 || d > 20 || !match_balanced(t, kind, d, canon) || (int)canon.size() > kFastMaxTables) return fp;
+    int shift_msg = -1;
+    for (size_t j = 0; j < canon.size(); j++) {
+        const TreeNode *nd = canon[j];
+        auto it = tab_of.find(nd);
+        if (it == tab_of.end() || it->second.second > (uint32_t)kFastTableStride) return fp;
+        for (auto &c : nd->child) if (!is_pow2(c->K) || c->K > 128) return fp;
+        if (!is_pow2(nd->K) || nd->K > 128) return fp;
+        const int sh0 = __builtin_ctz((unsigned)nd->child[0]->K);
+        if (j + 1 < canon.size()) {                     // internal node: both children carry messages
+            if (nd->child[0]->K != nd->child[1]->K) return fp;
+            if (shift_msg < 0) shift_msg = sh0; else if (shift_msg != sh0) return fp;
+        }
+        fp.P.tab_off[j] = (int32_t)it->second.first;
+        fp.P.tab_len[j] = (int32_t)it->second.second;
+        fp.P.tab_shift[j] = sh0;
+    }
+    fp.P.shift_msg = shift_msg < 0 ? 0 : shift_msg;
+    fp.P.n_tables = (int)canon.size();
+    fp.P.deg = d; fp.P.node_off = node_off; fp.P.n_nodes = n_nodes;
+    fp.ok = true;
+    return fp;
+}
+
+template <int KIND, bool CHECK, int DV>
+inline void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
+                               uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
+    const int waves = P.waves_per_group * P.G;
+    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
+                       tables, list, vn_ptr);
+}
+
+template <int KIND, bool CHECK, int... DVs>
+inline bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
+                             uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
+    bool done = false;
+    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr), done = true) : false), ...);
+    return done;
+}
+
+constexpr int kFastMaxDeg = 20;
+
+// launch one class; returns false when the degree has no instantiation
 template <int KIND>
-inline int launch_fast_tree_pass(hipStream_t, const PassParams &, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *,
-                                 uint32_t *, const Op *, const uint8_t *, const int32_t *, const int32_t *) {
-    return 0;
+inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
+                           uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr,
+                           int E, int N) {
+    P.G = G; P.E = E; P.N = N; P.nz = nz; P.check = check; P.write_hard = write_hard;
+    P.nodes_per_wave = nodes_per_wave;
+    P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
+    constexpr auto seq = std::make_integer_sequence<int, kFastMaxDeg>{};
+    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
+    return dispatch_vn_fast<KIND, false>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
 }
 
-inline int launch_fast_cn_minsum(hipStream_t, const PassParams &, uint8_t *, const uint32_t *, uint32_t *, const int32_t *,
-                                 const int32_t *, const int32_t *) {
-    return 0;
+// min-sum: one launch per degree class
+inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int node_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
+                           const uint32_t *state_w, uint32_t *vfail_w, const int32_t *list, const int32_t *cn_ptr, const int32_t *cn_idx) {
+    if (!is_pow2(nz) || nz > 64 || deg < 1 || deg > 32) return false;
+    FastParams P{};
+    P.n_nodes = n_nodes; P.node_off = node_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg;
+    P.nodes_per_wave = nodes_per_wave;
+    P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
+    const int waves = P.waves_per_group * G;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (deg <= 4) hipLaunchKernelGGL((cn_minsum_fast_kernel<4, 4>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else if (deg <= 8) hipLaunchKernelGGL((cn_minsum_fast_kernel<8, 2>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else if (deg <= 16) hipLaunchKernelGGL((cn_minsum_fast_kernel<16, 1>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else hipLaunchKernelGGL((cn_minsum_fast_kernel<32, 1>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    return true;
 }
-
-inline const char *fast_vn_kernel_name(int, int, const Program *) { return "tree_pass_kernel<VAR>"; }
-inline const char *fast_cn_kernel_name(int, int) { return "cn_minsum_generic_kernel"; }
 
 }  // namespace lutldpc

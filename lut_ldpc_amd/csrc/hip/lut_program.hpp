@@ -124,6 +124,8 @@ struct Program {
     int n_ops_naive = 0;     // look-ups of the reference's per-output walk
     std::vector<Op> ops;
     std::vector<uint8_t> tables;   // concatenated full tables
+    // LUT node -> {offset, length, parity-even offset} of its full table inside `tables`
+    std::vector<std::pair<const TreeNode *, std::array<uint32_t, 3>>> node_tabs;
     // for inputs that are forwarded unchanged to an output (cannot happen with LUT roots, kept
     // for completeness): out_from_input[i] = input slot or -1
 };
@@ -237,6 +239,7 @@ inline bool compile_program(const Tree &t, int kind, int d, Program &P, std::str
         if ((int)v.node->child.size() > kMaxChildren) { err = "node fan-in above 8"; return false; }
         if (!detail::expand_table(v.node, kind, P.tables, off, len, half, err)) return false;
         tabs[v.node] = {off, len, half};
+        P.node_tabs.push_back({v.node, {off, len, half}});
     }
     // liveness: last op index reading each value
     size_t nv = (size_t)P.n_in + b.vals.size();
