@@ -176,6 +176,14 @@ def main():
     if psc:
         vn_bytes += N * B                               # hard-decision rows written for the syndrome test
     it_exec = float(out_iters.abs().float().mean().item())
+    # HBM bytes per pass from the PMC counters (collected in separate rocprofv3 --pmc passes and
+    # committed under profiles/; valid only for the workload/batch/mode they were taken on)
+    traffic = None
+    for f in sorted((ROOT / "profiles").glob("*pmc_traffic*.json"), reverse=True):
+        t = json.loads(f.read_text())
+        if t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
+            traffic = t.get("vn_pass_hbm_bytes_per_pass")
+            break
     result = {
         "metric": "decoded codewords/sec, DVB-S2 N=64800 4-bit LUT 50-iter" if args.workload == "dvbs2" else "decoded codewords/sec",
         "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +196,7 @@ def main():
                    "mean_iterations_executed": it_exec, "parallelism": f"frames sharded over {world} GPU(s), counters all-reduced",
                    "kernels": dec.describe()},
         "roofline": {"bound": "hbm", "kernel": "vn_pass", "achieved": vn_bytes / (vn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": vn_bytes / (vn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": vn_bytes / (vn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": vn_bytes, "avg_launch_ms": vn_ms, "launches": vn["launches"]},
         "roofline_cn_pass": {"bound": "hbm", "achieved": cn_bytes / (cn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": cn_bytes / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": cn_bytes,
