@@ -102,6 +102,40 @@ int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int 
                                      int initial_message_mode, const int32_t *cha2msg_map,
                                      uint8_t *out_bits, int32_t *out_iters);
 
+/*
+ * Monte-Carlo front end + decode + error counting for B consecutive frames of one SNR point:
+ * the body of the frame loop of LDPC_BER_Sim::sim_snr_point (src/LDPC_BER_Sim.cpp:260-286)
+ * without the stop rule, which stays with the caller (it needs the frames in order).
+ *
+ * The channel is described by the partition of the received value into cells (see
+ * lut_ldpc_amd/csrc/hip/kernels_frontend.hpp): n_cells cells with cumulative probabilities
+ * thr[j] = floor(2^64 * P(cell <= j | bit 0 sent)) for j < n_cells-1 and, per cell, the channel
+ * label, initial message label and slicer sign for a sent 0 and the labels of the mirrored cell
+ * for a sent 1.  Frame f of the SNR point uses the Philox4x32-10 stream
+ * (key = seed, counter = (f_lo, f_hi, bit-pair index, stream)), so any split of the frame range
+ * over calls / GPUs generates the same frames.
+ *   codewords   host [B*nvar] sent bits, or NULL for the all-zero codeword
+ *   K_info      number of leading bits counted as data bits (nvar - rank(H))
+ *   frame_stats host [B*4] int32: {lut_decode return value, frame error 0/1, data bit errors,
+ *               uncoded (slicer) bit errors over all nvar bits}
+ */
+typedef struct {
+    int32_t n_cells;
+    const uint64_t *thr;        /* n_cells-1 */
+    const uint8_t *cha_label;   /* n_cells each */
+    const uint8_t *msg_label;
+    const uint8_t *slicer_neg;
+    const uint8_t *cha_label_mirror;
+    const uint8_t *msg_label_mirror;
+} lutldpc_channel_cells;
+
+int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream,
+                              uint64_t frame0, int B, const uint8_t *codewords, int K_info, int32_t *frame_stats);
+
+/* The labels the sampler would produce for those frames (host, frame-major [B*nvar]); for tests. */
+int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream,
+                                  uint64_t frame0, int B, const uint8_t *codewords, uint8_t *cha, uint8_t *msg0);
+
 /* The decoder's HIP stream (hipStream_t as void*), for callers that enqueue their own work. */
 void *lutldpc_decoder_stream(lutldpc_decoder *d);
 

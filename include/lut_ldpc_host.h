@@ -55,6 +55,44 @@ int lutldpc_codec_lut_decode_batch(lutldpc_codec *c, const uint8_t *cha, const u
 /* LDPC_Code_LUT::encode: info[K] -> codeword[nvar] (needs with_generator) */
 int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codeword);
 
+/* One batch of the Monte-Carlo loop (front end + decode + error counting on the device) at Eb/N0
+ * snr_db: frames frame0 .. frame0+B-1 of stream `stream` (= index of the SNR point).  The channel
+ * cells are derived from the codec's boundaries; with zero_codeword = 0 the data bits come from the
+ * Philox stream and are encoded on the host (needs with_generator).  stats: host [B*4] int32 as in
+ * lutldpc_decoder_sim_batch. */
+int lutldpc_codec_sim_batch(lutldpc_codec *c, double snr_db, uint64_t seed, uint32_t stream, uint64_t frame0, int B,
+                            int zero_codeword, int32_t *stats);
+/* the labels (and sent codewords, may be NULL) of those frames, for tests */
+int lutldpc_codec_sample_labels(lutldpc_codec *c, double snr_db, uint64_t seed, uint32_t stream, uint64_t frame0, int B,
+                                int zero_codeword, uint8_t *cha, uint8_t *msg0, uint8_t *codewords);
+/* the channel cell table for that SNR (see lut_ldpc_hip.h): returns n_cells; arrays need 72 entries */
+int lutldpc_codec_channel_cells(lutldpc_codec *c, double snr_db, uint64_t *thr, uint8_t *cha, uint8_t *msg, uint8_t *neg,
+                                uint8_t *cha_m, uint8_t *msg_m);
+
+/* ber_sim: load() + run() [+ save()] of LDPC_BER_Sim_LUT for a parameter file (prog/ber_sim.cpp).
+ * Returns the number of SNR points written to snr[cap] / counters[cap*5]
+ * ({frames, data bits, frame errors, data bit errors, uncoded bit errors} per point), <0 on error. */
+int lutldpc_ber_sim_run(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device,
+                        int save_results, int quiet, double *snr, int64_t *counters, int cap);
+/* The same simulation object driven step by step, for callers that shard the frames of an SNR point
+ * over several processes / GPUs (lut_ldpc_amd/ber_sim.py): create = constructor + load(). */
+typedef struct lutldpc_bersim lutldpc_bersim;
+int lutldpc_bersim_create(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device,
+                          lutldpc_bersim **out);
+int lutldpc_bersim_destroy(lutldpc_bersim *s);
+/* info[8] = {n_snr, Nframes, Nfers, nvar, ninfo, max_iter, zero_codeword, batch_frames}; limits[2] = {ber_min, fer_min} */
+int lutldpc_bersim_info(lutldpc_bersim *s, int64_t *info, double *limits, double *snr, int snr_cap);
+/* frames frame0..frame0+B-1 of SNR point snr_index -> stats[B*4] (see lutldpc_decoder_sim_batch) */
+int lutldpc_bersim_batch(lutldpc_bersim *s, int snr_index, int64_t frame0, int B, int32_t *stats);
+/* results.add_snr_point / save_runtime + save() */
+int lutldpc_bersim_add_point(lutldpc_bersim *s, double snr, const int64_t *counters5);
+int lutldpc_bersim_save(lutldpc_bersim *s, double runtime_s);
+/* the results-file path save() writes (copied into buf when cap suffices; returns needed length) */
+int64_t lutldpc_bersim_results_path(lutldpc_bersim *s, char *buf, int64_t cap);
+
+/* the command line itself */
+int lutldpc_ber_sim_main(int argc, char **argv);
+
 /* LDPC_DE_LUT::bisec_search for an ensemble given by its active degrees (prog/de_sim.cpp:137-260
  * set-up: auto trees, no reuse, uniform resolution).  Returns the bisection count, <0 on error. */
 int lutldpc_de_threshold(const int32_t *dl, const double *lam, int nl, const int32_t *dr, const double *rho, int nr,

@@ -101,3 +101,23 @@ for _name, (_res, _args) in _HOST_SIGNATURES.items():
     if hasattr(lib, _name):
         _fn = getattr(lib, _name)
         _fn.restype, _fn.argtypes = _res, _args
+
+_u64p, _i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+_SIM_SIGNATURES = {
+    "lutldpc_codec_sim_batch": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, _ip]),
+    "lutldpc_codec_sample_labels": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, _u8p, _u8p, _u8p]),
+    "lutldpc_codec_channel_cells": (C.c_int, [_vp, C.c_double, _u64p, _u8p, _u8p, _u8p, _u8p, _u8p]),
+    "lutldpc_ber_sim_run": (C.c_int, [_cp, _cp, C.c_int, _cp, C.c_int, C.c_int, C.c_int, _dp, _i64p, C.c_int]),
+    "lutldpc_ber_sim_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "lutldpc_bersim_create": (C.c_int, [_cp, _cp, C.c_int, _cp, C.c_int, C.POINTER(_vp)]),
+    "lutldpc_bersim_destroy": (C.c_int, [_vp]),
+    "lutldpc_bersim_info": (C.c_int, [_vp, _i64p, _dp, _dp, C.c_int]),
+    "lutldpc_bersim_batch": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _ip]),
+    "lutldpc_bersim_add_point": (C.c_int, [_vp, C.c_double, _i64p]),
+    "lutldpc_bersim_save": (C.c_int, [_vp, C.c_double]),
+    "lutldpc_bersim_results_path": (C.c_int64, [_vp, C.c_char_p, C.c_int64]),
+}
+for _name, (_res, _args) in _SIM_SIGNATURES.items():
+    if hasattr(lib, _name):
+        _fn = getattr(lib, _name)
+        _fn.restype, _fn.argtypes = _res, _args

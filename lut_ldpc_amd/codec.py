@@ -131,6 +131,27 @@ class Codec:
         check(lib.lutldpc_codec_lut_decode_batch(self._h, _p(cha, C.c_uint8), _p(msg0, C.c_uint8), B, _p(bits, C.c_uint8), _p(iters, C.c_int32)))
         return bits, iters
 
+    # ---- Monte-Carlo front end ------------------------------------------------------------------------
+    def sim_batch(self, snr_db, seed, stream, frame0, B, zero_codeword=True) -> np.ndarray:
+        """{iters, frame error, data bit errors, uncoded errors} of frames frame0..frame0+B-1 (device sampler + decode)."""
+        stats = np.empty((B, 4), np.int32)
+        check(lib.lutldpc_codec_sim_batch(self._h, float(snr_db), int(seed), int(stream), int(frame0), int(B), int(zero_codeword), _p(stats, C.c_int32)))
+        return stats
+
+    def sample_labels(self, snr_db, seed, stream, frame0, B, zero_codeword=True):
+        cha, msg = np.empty((B, self.nvar), np.uint8), np.empty((B, self.nvar), np.uint8)
+        cw = np.empty((B, self.nvar), np.uint8)
+        check(lib.lutldpc_codec_sample_labels(self._h, float(snr_db), int(seed), int(stream), int(frame0), int(B), int(zero_codeword),
+                                              _p(cha, C.c_uint8), _p(msg, C.c_uint8), _p(cw, C.c_uint8)))
+        return cha, msg, cw
+
+    def channel_cells(self, snr_db):
+        thr = np.zeros(72, np.uint64)
+        arrs = [np.zeros(72, np.uint8) for _ in range(5)]
+        n = lib.lutldpc_codec_channel_cells(self._h, float(snr_db), _p(thr, C.c_uint64), *[_p(a, C.c_uint8) for a in arrs])
+        check(min(n, 0))
+        return {"thr": thr[:n - 1], "cha": arrs[0][:n], "msg": arrs[1][:n], "neg": arrs[2][:n], "cha_m": arrs[3][:n], "msg_m": arrs[4][:n]}
+
     def encode(self, info):
         info = np.ascontiguousarray(info, np.uint8)
         assert info.shape == (self.ninfo,)

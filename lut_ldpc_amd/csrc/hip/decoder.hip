@@ -8,6 +8,7 @@
 #include "kernels_common.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
+#include "kernels_frontend.hpp"
 #include "lut_program.hpp"
 
 #include <algorithm>
@@ -98,6 +99,8 @@ struct lutldpc_decoder {
     DevBuf<int32_t> d_out_iters;
     DevBuf<double> d_llr, d_qb_cha, d_qb_msg;
     DevBuf<int32_t> d_map;
+    DevBuf<uint8_t> d_codewords;
+    DevBuf<int32_t> d_stats;
     // ---- tuning
     int nodes_per_block = 16;
     int nodes_per_wave = 8;     // specialised kernels
@@ -384,27 +387,16 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     return LUTLDPC_OK;
 }
 
-// The batched lut_decode (src/LDPC_Code_LUT.cpp:259-353) on device-resident frame-major labels.
-int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B, uint8_t *d_out_bits, int32_t *d_out_iters) {
-    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
-    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
-    HIP_TRY(hipSetDevice(d->device));
-    int rc = ensure_batch(d, B);
-    if (rc) return rc;
+// Core: decode the B frames whose labels are already in tile layout (d_cha_t / d_msg0_t).
+// Leaves the decided bits in d_hard (tile layout) and the iteration codes in d_iters.
+int decode_tiles(lutldpc_decoder *d, int B) {
+    int rc;
     const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames;
     const int N = d->nvar, E = d->E, I = d->max_iters;
     const int last_set = d->iter_set[(size_t)(I - 1)];
     if (!d->dec_plan[(size_t)last_set].valid)
         return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
-
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
-    {
-        Timed t(d, LUTLDPC_K_LAYOUT);
-        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
-        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha);
-        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]);
-        LAUNCH_CHECK();
-    }
     if (d->pisc) {   // :275-279
         {
             Timed t(d, LUTLDPC_K_LAYOUT);
@@ -438,13 +430,71 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
     if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
     if ((rc = launch_syndrome(d, G))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
+    if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
+    return LUTLDPC_OK;
+}
+
+// The batched lut_decode (src/LDPC_Code_LUT.cpp:259-353) on device-resident frame-major labels.
+int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B, uint8_t *d_out_bits, int32_t *d_out_iters) {
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
+    HIP_TRY(hipSetDevice(d->device));
+    int rc = ensure_batch(d, B);
+    if (rc) return rc;
+    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames;
+    const int N = d->nvar;
+    {
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
+        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha);
+        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]);
+        LAUNCH_CHECK();
+    }
+    if ((rc = decode_tiles(d, B))) return rc;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
         hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p, d_out_bits, B, N);
         LAUNCH_CHECK();
         HIP_TRY(hipMemcpyAsync(d_out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToDevice, d->stream));
     }
-    if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
+    return LUTLDPC_OK;
+}
+
+int fill_cells(const lutldpc_channel_cells *c, const lutldpc_decoder *d, ChannelCells &C) {
+    if (!c || !c->thr || !c->cha_label || !c->msg_label || !c->slicer_neg || !c->cha_label_mirror || !c->msg_label_mirror)
+        return fail(LUTLDPC_ERR_ARG, "channel cells: NULL member");
+    if (c->n_cells < 1 || c->n_cells > kMaxCells) return fail(LUTLDPC_ERR_ARG, "channel cells: n_cells outside [1,72]");
+    std::memset(&C, 0, sizeof(C));
+    C.n_cells = c->n_cells;
+    for (int j = 0; j < c->n_cells; j++) {
+        if (j < c->n_cells - 1) { C.thr[j] = c->thr[j]; if (j && c->thr[j] < c->thr[j - 1]) return fail(LUTLDPC_ERR_ARG, "channel cells: thresholds must ascend"); }
+        if (c->cha_label[j] >= d->Nq_Cha || c->cha_label_mirror[j] >= d->Nq_Cha || c->msg_label[j] >= d->Nq_Msg[0] || c->msg_label_mirror[j] >= d->Nq_Msg[0])
+            return fail(LUTLDPC_ERR_ARG, "channel cells: label outside its alphabet");
+        C.cha[j] = c->cha_label[j]; C.msg[j] = c->msg_label[j]; C.neg[j] = c->slicer_neg[j] ? 1 : 0;
+        C.cha_m[j] = c->cha_label_mirror[j]; C.msg_m[j] = c->msg_label_mirror[j];
+    }
+    return LUTLDPC_OK;
+}
+
+// sampler -> d_cha_t / d_msg0_t (tile layout); stats zeroed and slicer errors accumulated
+int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint32_t stream, uint64_t frame0, int B, const uint8_t *codewords_host) {
+    int rc = ensure_batch(d, B);
+    if (rc) return rc;
+    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+    HIP_TRY(d->d_stats.alloc((size_t)Bpad * 4));
+    HIP_TRY(hipMemsetAsync(d->d_stats.p, 0, sizeof(int32_t) * (size_t)Bpad * 4, d->stream));
+    const uint8_t *cw = nullptr;
+    if (codewords_host) {
+        HIP_TRY(d->d_codewords.alloc((size_t)B * N));
+        HIP_TRY(hipMemcpyAsync(d->d_codewords.p, codewords_host, (size_t)B * N, hipMemcpyHostToDevice, d->stream));
+        cw = d->d_codewords.p;
+    }
+    Timed t(d, LUTLDPC_K_FRONTEND);
+    const int ppt = 8, npairs = (N + 1) / 2;
+    dim3 grid((unsigned)((npairs + 4 * ppt - 1) / (4 * ppt)), (unsigned)G);
+    hipLaunchKernelGGL(sample_labels_kernel, grid, dim3(256), 0, d->stream, C, (uint32_t)seed, (uint32_t)(seed >> 32), stream, frame0, B, N, cw,
+                       d->d_cha_t.p, d->d_msg0_t.p, d->d_stats.p, ppt);
+    LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
 
@@ -554,7 +604,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
-        d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release();
+        d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
     }
     delete d;
@@ -621,6 +671,53 @@ int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int 
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_bits, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipMemcpyAsync(out_iters, d->d_out_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream, uint64_t frame0, int B,
+                              const uint8_t *codewords, int K_info, int32_t *frame_stats) {
+    if (!d || !frame_stats) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0 || K_info < 0 || K_info > d->nvar) return fail(LUTLDPC_ERR_ARG, "bad B / K_info");
+    ChannelCells C;
+    int rc = fill_cells(cells, d, C);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->device));
+    if ((rc = sample_tiles(d, C, seed, stream, frame0, B, codewords))) return rc;
+    if ((rc = decode_tiles(d, B))) return rc;
+    {
+        Timed t(d, LUTLDPC_K_FRONTEND);
+        const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, rpw = 64;
+        const int rows = K_info > 0 ? K_info : 1;
+        hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+                           codewords ? d->d_codewords.p : nullptr, B, d->nvar, K_info, d->d_iters.p, d->d_stats.p, rpw);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipMemcpyAsync(frame_stats, d->d_stats.p, sizeof(int32_t) * (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LUTLDPC_OK;
+}
+
+int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream, uint64_t frame0, int B,
+                                  const uint8_t *codewords, uint8_t *cha, uint8_t *msg0) {
+    if (!d || !cha || !msg0) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
+    if (B <= 0) return fail(LUTLDPC_ERR_ARG, "B must be positive");
+    ChannelCells C;
+    int rc = fill_cells(cells, d, C);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->device));
+    if ((rc = sample_tiles(d, C, seed, stream, frame0, B, codewords))) return rc;
+    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+    const size_t n = (size_t)B * N;
+    HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n));
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
+    hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_in_cha.p, B, N);
+    hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_in_msg.p, B, N);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(cha, d->d_in_cha.p, n, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(msg0, d->d_in_msg.p, n, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     return LUTLDPC_OK;
 }

@@ -1,0 +1,136 @@
+// kernels_frontend.hpp -- Monte-Carlo front end on the device: the per-frame work of
+// LDPC_BER_Sim::sim_snr_point (src/LDPC_BER_Sim.cpp:260-286) other than the decode itself.
+//
+// The reference draws N Gaussian samples per frame, forms LLR = 4x/N0 and quantises them
+// (BPSK + AWGN_Channel + demodulate_soft_bits + quant_nonlin).  All the decoder ever sees of a
+// received value x is (channel label, initial message label, slicer sign), i.e. which cell of the
+// partition of the real line by the thresholds {qb_Cha*N0/4} u {qb_Msg*N0/4} u {0} it fell
+// into.  The sampler therefore draws the CELL directly: one 64-bit uniform per code bit is
+// compared against the integer cumulative cell probabilities (computed once per SNR point on the
+// host from the Gaussian cdf).  This is an exact sampler of the same joint distribution (up to
+// the 2^-64 resolution of the thresholds), needs no transcendental on the device and -- because
+// everything after the thresholds is integer arithmetic -- gives bit-identical label streams on
+// the GPU and in the CPU oracle.  (The IT++ random stream itself cannot be reproduced: SURVEY F5.)
+//
+// Random numbers: Philox4x32-10 (Salmon et al., SC'11), key = seed, counter =
+// (frame index lo, hi, code-bit pair index, stream id); the four output words give the two
+// 64-bit uniforms of code bits 2p and 2p+1.  Frames are therefore addressable: any sharding of
+// the frame range over GPUs produces the same frames.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace lutldpc {
+
+constexpr int kMaxCells = 72;      // 2*(Nq-1)+1 thresholds for Nq <= 32 ... generous
+
+struct ChannelCells {
+    int32_t n_cells;
+    int32_t pad;
+    uint64_t thr[kMaxCells];       // thr[j] = floor(2^64 * P(cell <= j | bit 0)), j < n_cells-1
+    uint8_t cha[kMaxCells];        // labels of each cell when bit 0 was sent
+    uint8_t msg[kMaxCells];
+    uint8_t neg[kMaxCells];        // 1: x < 0 (slicer decides bit 1)
+    uint8_t cha_m[kMaxCells];      // labels of the mirrored cell (bit 1 was sent: x -> -x)
+    uint8_t msg_m[kMaxCells];
+};
+
+struct Philox {
+    __host__ __device__ static inline void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __host__ __device__ static inline void gen(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+};
+
+__device__ __forceinline__ int cell_of(const ChannelCells &C, uint64_t u) {
+    int j = 0;
+    for (int k = 0; k < C.n_cells - 1; k++) j += (u >= C.thr[k]) ? 1 : 0;
+    return j;
+}
+
+// Writes cha_t / msg0_t rows (tile layout) for B frames starting at global frame index frame0 and
+// adds the slicer errors of each frame to stats[f][3].  One thread = 4 frames x a run of code-bit
+// pairs.  codewords (frame-major [B][N], may be null = all-zero codeword) holds the sent bits.
+__global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint64_t frame0,
+                                                            int B, int N, const uint8_t *__restrict__ codewords, uint8_t *__restrict__ cha_t,
+                                                            uint8_t *__restrict__ msg_t, int32_t *__restrict__ stats, int pairs_per_thread)
+{
+    const int lane = threadIdx.x & 63, g = blockIdx.y;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int npairs = (N + 1) / 2;
+    int p0 = w * pairs_per_thread, p1 = p0 + pairs_per_thread;
+    if (p1 > npairs) p1 = npairs;
+    int unc[4] = {0, 0, 0, 0};
+    for (int p = p0; p < p1; p++) {
+        uint32_t ca[2] = {0, 0}, ms[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int fl = g * kTileFrames + lane * 4 + j;          // frame within the batch
+            if (fl >= B) continue;                                  // pad frames keep label 0
+            const uint64_t f = frame0 + (uint64_t)fl;
+            uint32_t c[4] = {(uint32_t)f, (uint32_t)(f >> 32), (uint32_t)p, stream};
+            Philox::gen(c, seed_lo, seed_hi);
+            const uint64_t u[2] = {((uint64_t)c[1] << 32) | c[0], ((uint64_t)c[3] << 32) | c[2]};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int v = 2 * p + h;
+                if (v >= N) continue;
+                const int cell = cell_of(C, u[h]);
+                const int bit = codewords ? codewords[(size_t)fl * N + v] : 0;
+                const uint32_t a = bit ? C.cha_m[cell] : C.cha[cell], m = bit ? C.msg_m[cell] : C.msg[cell];
+                const int sl = bit ? (C.neg[cell] ^ 1) : C.neg[cell];     // slicer decision
+                unc[j] += (sl != bit);
+                ca[h] |= a << (8 * j);
+                ms[h] |= m << (8 * j);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int v = 2 * p + h;
+            if (v >= N) continue;
+            *reinterpret_cast<uint32_t *>(cha_t + ((size_t)g * N + v) * kTileFrames + lane * 4) = ca[h];
+            *reinterpret_cast<uint32_t *>(msg_t + ((size_t)g * N + v) * kTileFrames + lane * 4) = ms[h];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int fl = g * kTileFrames + lane * 4 + j;
+        if (fl < B && unc[j]) atomicAdd(&stats[(size_t)fl * 4 + 3], unc[j]);
+    }
+}
+
+// stats[f] = {iteration code, frame error, data bit errors, uncoded bit errors}: compares the decided
+// bits of the first K positions with the sent ones (BERC / BLERC of src/LDPC_BER_Sim.cpp:284-286)
+__global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ codewords, int B, int N, int K,
+                                                           const int32_t *__restrict__ iters, int32_t *__restrict__ stats, int rows_per_wave)
+{
+    const int lane = threadIdx.x & 63, g = blockIdx.y;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int v0 = w * rows_per_wave, v1 = v0 + rows_per_wave;
+    if (v1 > K) v1 = K;
+    int err[4] = {0, 0, 0, 0};
+    for (int v = v0; v < v1; v++) {
+        const uint32_t h = *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + v) * kTileFrames + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int fl = g * kTileFrames + lane * 4 + j;
+            const int sent = (codewords && fl < B) ? codewords[(size_t)fl * N + v] : 0;
+            err[j] += (int)((h >> (8 * j)) & 1u) != sent;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int fl = g * kTileFrames + lane * 4 + j;
+        if (fl < B && err[j]) { atomicAdd(&stats[(size_t)fl * 4 + 2], err[j]); atomicOr(&stats[(size_t)fl * 4 + 1], 1); }
+        if (fl < B && v0 == 0) stats[(size_t)fl * 4 + 0] = iters[fl];
+    }
+}
+
+}  // namespace lutldpc

@@ -1,6 +1,10 @@
 // host_capi.cpp -- C-ABI of include/lut_ldpc_host.h over the C++ host classes.
 #include "lut_ldpc_host.h"
 #include "ldpc_code_lut.hpp"
+#include "ber_sim_driver.hpp"
+
+#include <cmath>
+#include <vector>
 
 #include <cstring>
 #include <memory>
@@ -149,6 +153,142 @@ int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codewor
         std::memcpy(codeword, out.data(), out.size());
         return LUTLDPC_OK;
     });
+}
+
+namespace {
+ChannelCellTable cells_for(lutldpc_codec *c, double snr_db) {
+    const double N0 = std::pow(10.0, -snr_db / 10.0) / c->C->get_rate();
+    const int mode = c->C->get_initial_message_mode() == LDPC_Code_LUT::QCHA ? 1 : 0;
+    return make_channel_cells(N0, c->C->get_qb_Cha(), c->C->get_qb_Msg(), mode, c->C->get_Nq_Cha_2_Nq_Msg_map());
+}
+void make_codewords(lutldpc_codec *c, uint64_t seed, uint32_t stream, uint64_t frame0, int B, std::vector<unsigned char> &cw) {
+    const int N = c->C->get_nvar(), K = c->C->get_ninfo();
+    cw.resize((size_t)B * N);
+    bvec info((size_t)K), one;
+    for (int i = 0; i < B; i++) {
+        random_info_bits(seed, stream, frame0 + (uint64_t)i, K, info.data());
+        c->C->encode(info, one);
+        std::memcpy(&cw[(size_t)i * N], one.data(), (size_t)N);
+    }
+}
+}  // namespace
+
+int lutldpc_codec_sim_batch(lutldpc_codec *c, double snr_db, uint64_t seed, uint32_t stream, uint64_t frame0, int B, int zero_codeword, int32_t *stats) {
+    return guarded([&] {
+        if (!c || !stats || B <= 0) throw std::invalid_argument("NULL / bad argument");
+        const ChannelCellTable cells = cells_for(c, snr_db);
+        const lutldpc_channel_cells view = cells.view();
+        std::vector<unsigned char> cw;
+        if (!zero_codeword) make_codewords(c, seed, stream, frame0, B, cw);
+        return lutldpc_decoder_sim_batch(c->C->device_handle(), &view, seed, stream, frame0, B, zero_codeword ? nullptr : cw.data(), c->C->get_ninfo(), stats);
+    });
+}
+
+int lutldpc_codec_sample_labels(lutldpc_codec *c, double snr_db, uint64_t seed, uint32_t stream, uint64_t frame0, int B, int zero_codeword,
+                                uint8_t *cha, uint8_t *msg0, uint8_t *codewords) {
+    return guarded([&] {
+        if (!c || !cha || !msg0 || B <= 0) throw std::invalid_argument("NULL / bad argument");
+        const ChannelCellTable cells = cells_for(c, snr_db);
+        const lutldpc_channel_cells view = cells.view();
+        std::vector<unsigned char> cw;
+        if (!zero_codeword) make_codewords(c, seed, stream, frame0, B, cw);
+        if (codewords) { if (zero_codeword) std::memset(codewords, 0, (size_t)B * c->C->get_nvar()); else std::memcpy(codewords, cw.data(), cw.size()); }
+        return lutldpc_decoder_sample_labels(c->C->device_handle(), &view, seed, stream, frame0, B, zero_codeword ? nullptr : cw.data(), cha, msg0);
+    });
+}
+
+int lutldpc_codec_channel_cells(lutldpc_codec *c, double snr_db, uint64_t *thr, uint8_t *cha, uint8_t *msg, uint8_t *neg, uint8_t *cha_m, uint8_t *msg_m) {
+    int n = 0;
+    int rc = guarded([&] {
+        if (!c || !thr || !cha || !msg || !neg || !cha_m || !msg_m) throw std::invalid_argument("NULL argument");
+        const ChannelCellTable t = cells_for(c, snr_db);
+        n = (int)t.cha.size();
+        if (n > 72) throw std::invalid_argument("more than 72 cells");
+        std::memcpy(thr, t.thr.data(), sizeof(uint64_t) * t.thr.size());
+        std::memcpy(cha, t.cha.data(), (size_t)n); std::memcpy(msg, t.msg.data(), (size_t)n); std::memcpy(neg, t.neg.data(), (size_t)n);
+        std::memcpy(cha_m, t.cha_m.data(), (size_t)n); std::memcpy(msg_m, t.msg_m.data(), (size_t)n);
+        return LUTLDPC_OK;
+    });
+    return rc == LUTLDPC_OK ? n : rc;
+}
+
+int lutldpc_ber_sim_run(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device, int save_results, int quiet,
+                        double *snr, int64_t *counters, int cap) {
+    int n = 0;
+    int rc = guarded([&] {
+        if (!params_path || !base_dir) throw std::invalid_argument("NULL argument");
+        LDPC_BER_Sim_LUT sim(params_path, base_dir);
+        sim.rand_seed = seed; sim.device = device; sim.quiet = quiet != 0;
+        if (custom_name) sim.append_custom_name(custom_name);
+        sim.load();
+        sim.run();
+        if (save_results) sim.save();
+        const LDPC_BER_Sim_Results &r = sim.results;
+        n = (int)r.sim_SNRdB.size();
+        for (int i = 0; i < n && i < cap; i++) {
+            if (snr) snr[i] = r.sim_SNRdB[(size_t)i];
+            if (counters) {
+                counters[i * 5 + 0] = r.sim_Nframes[(size_t)i]; counters[i * 5 + 1] = r.sim_Ndatabits[(size_t)i];
+                counters[i * 5 + 2] = r.sim_frame_errors[(size_t)i]; counters[i * 5 + 3] = r.sim_data_bit_errors[(size_t)i];
+                counters[i * 5 + 4] = r.sim_uncoded_bit_errors[(size_t)i];
+            }
+        }
+        return LUTLDPC_OK;
+    });
+    return rc == LUTLDPC_OK ? n : rc;
+}
+
+int lutldpc_ber_sim_main(int argc, char **argv) { return ber_sim_main(argc, argv); }
+
+struct lutldpc_bersim { std::unique_ptr<LDPC_BER_Sim_LUT> sim; };
+
+int lutldpc_bersim_create(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device, lutldpc_bersim **out) {
+    return guarded([&] {
+        if (!params_path || !base_dir || !out) throw std::invalid_argument("NULL argument");
+        std::unique_ptr<lutldpc_bersim> s(new lutldpc_bersim);
+        s->sim.reset(new LDPC_BER_Sim_LUT(params_path, base_dir));
+        s->sim->rand_seed = seed; s->sim->device = device; s->sim->quiet = true;
+        if (custom_name) s->sim->append_custom_name(custom_name);
+        s->sim->load();
+        *out = s.release();
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_bersim_destroy(lutldpc_bersim *s) { delete s; return LUTLDPC_OK; }
+int lutldpc_bersim_info(lutldpc_bersim *s, int64_t *info, double *limits, double *snr, int snr_cap) {
+    return guarded([&] {
+        if (!s || !info || !limits) throw std::invalid_argument("NULL argument");
+        LDPC_BER_Sim_LUT &m = *s->sim;
+        info[0] = (int64_t)m.SNRdB.size(); info[1] = (int64_t)m.Nframes; info[2] = m.Nfers; info[3] = m.get_codeword_length();
+        info[4] = m.get_dataword_length(); info[5] = m.max_iter; info[6] = m.zero_codeword ? 1 : 0; info[7] = m.batch_frames;
+        limits[0] = m.ber_min; limits[1] = m.fer_min;
+        if (snr) for (int i = 0; i < (int)m.SNRdB.size() && i < snr_cap; i++) snr[i] = m.SNRdB[(size_t)i];
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_bersim_batch(lutldpc_bersim *s, int snr_index, int64_t frame0, int B, int32_t *stats) {
+    return guarded([&] {
+        if (!s || !stats || B <= 0) throw std::invalid_argument("NULL / bad argument");
+        if (snr_index < 0 || snr_index >= (int)s->sim->SNRdB.size()) throw std::invalid_argument("snr_index out of range");
+        s->sim->sim_batch(s->sim->SNRdB[(size_t)snr_index], snr_index, frame0, B, reinterpret_cast<FrameStats *>(stats));
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_bersim_add_point(lutldpc_bersim *s, double snr, const int64_t *c) {
+    return guarded([&] {
+        if (!s || !c) throw std::invalid_argument("NULL argument");
+        s->sim->results.add_snr_point(snr, c[0], c[1], c[2], c[3], c[4]);
+        return LUTLDPC_OK;
+    });
+}
+int lutldpc_bersim_save(lutldpc_bersim *s, double runtime_s) {
+    return guarded([&] { if (!s) throw std::invalid_argument("NULL argument"); s->sim->results.save_runtime(runtime_s); s->sim->save(); return LUTLDPC_OK; });
+}
+int64_t lutldpc_bersim_results_path(lutldpc_bersim *s, char *buf, int64_t cap) {
+    if (!s) return 0;
+    std::string p;
+    if (guarded([&] { p = s->sim->results_file_path(); return LUTLDPC_OK; }) != LUTLDPC_OK) return 0;
+    return copy_out(p, buf, cap);
 }
 
 int lutldpc_de_threshold(const int32_t *dl, const double *lam, int nl, const int32_t *dr, const double *rho, int nr, int qbits_cha, int qbits_msg,

@@ -63,6 +63,12 @@ def lib() -> C.CDLL:
             "or_api_codec_tree_eval": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip]),
             "or_api_codec_tree_info": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip, ip]),
             "or_api_codec_n_sets": (C.c_int, [vp, C.c_int]),
+            "or_sim_channel_cells": (C.c_int, [vp, C.c_double, C.c_double, C.POINTER(C.c_uint64), u8p, u8p, u8p, u8p, u8p]),
+            "or_sim_sample_labels": (None, [vp, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u8p, u8p, u8p, ip]),
+            "or_sim_snr_point": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint32, C.c_int64, C.c_int, C.c_double,
+                                           C.c_double, u8p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+            "or_sim_info_bits": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u8p]),
+            "or_code_from_graph": (vp, [C.c_int, C.c_int, ip, ip, ip]),
             "or_api_quant_nonlin_vec": (None, [dp, C.c_int, dp, C.c_int, u8p]),
             "or_api_de_threshold": (C.c_int, [ip, dp, C.c_int, ip, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, cp, cp,
                                               C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, dp]),
@@ -100,10 +106,15 @@ def readme_tree(tmpl="riim/im/m///iim/m//im/m////c//", m1=3.0, m2=2.0, nq_in=16,
 
 
 class Code:
-    """Parity-check matrix loaded from an alist file (oracle side)."""
+    """Parity-check matrix loaded from an alist file (oracle side), or rebuilt from graph arrays."""
 
-    def __init__(self, alist_path):
-        self._h = lib().or_code_load_alist(str(alist_path).encode())
+    def __init__(self, alist_path=None, graph=None):
+        if graph is not None:
+            nvar, nchk, dv, dc, cn = graph
+            dv, dc, cn = (np.ascontiguousarray(a, np.int32) for a in (dv, dc, cn))
+            self._h = lib().or_code_from_graph(int(nvar), int(nchk), _ip(dv), _ip(dc), _ip(cn))
+        else:
+            self._h = lib().or_code_load_alist(str(alist_path).encode())
         if not self._h:
             raise FileNotFoundError(f"cannot load alist {alist_path}")
         n, m, e = C.c_int(), C.c_int(), C.c_int()
@@ -233,9 +244,39 @@ class Codec:
     def n_sets(self, chk=False) -> int:
         return lib().or_api_codec_n_sets(self._h, int(chk))
 
+    # ---- Monte-Carlo front end (oracle/or_sim.c) ---------------------------------------------------
+    def channel_cells(self, snr_db: float, rate: float):
+        thr = np.zeros(80, np.uint64)
+        arrs = [np.zeros(80, np.uint8) for _ in range(5)]
+        n = lib().or_sim_channel_cells(self._h, snr_db, rate, thr.ctypes.data_as(C.POINTER(C.c_uint64)), *[_u8p(a) for a in arrs])
+        return {"thr": thr[:n - 1], "cha": arrs[0][:n], "msg": arrs[1][:n], "neg": arrs[2][:n], "cha_m": arrs[3][:n], "msg_m": arrs[4][:n]}
+
+    def sample_labels(self, snr_db, rate, seed, stream, frame0, B, codewords=None):
+        N = self.code.nvar
+        cha, msg = np.zeros((B, N), np.uint8), np.zeros((B, N), np.uint8)
+        unc = np.zeros(B, np.int32)
+        cw = None if codewords is None else np.ascontiguousarray(codewords, np.uint8)
+        lib().or_sim_sample_labels(self._h, snr_db, rate, seed, stream, frame0, B, _u8p(cw) if cw is not None else None, _u8p(cha), _u8p(msg), _ip(unc))
+        return cha, msg, unc
+
+    def sim_snr_point(self, snr_db, rate, K, seed, stream, nframes, nfers=20, ber_min=1e-7, fer_min=1e-5, codewords=None):
+        counters = np.zeros(5, np.int64)
+        per = np.zeros((nframes, 4), np.int32)
+        cw = None if codewords is None else np.ascontiguousarray(codewords, np.uint8)
+        stop = lib().or_sim_snr_point(self._h, snr_db, rate, K, seed, stream, nframes, nfers, ber_min, fer_min,
+                                      _u8p(cw) if cw is not None else None, counters.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      per.ctypes.data_as(C.POINTER(C.c_int32)))
+        return counters, per[:counters[0]], bool(stop)
+
     def syndrome_ok(self, bits: np.ndarray) -> bool:
         b = np.ascontiguousarray(bits, np.uint8)
         return bool(lib().or_codec_syndrome_ok(self._h, _u8p(b)))
+
+
+def info_bits(seed, stream, frame, K) -> np.ndarray:
+    out = np.zeros(K, np.uint8)
+    lib().or_sim_info_bits(seed, stream, frame, K, _u8p(out))
+    return out
 
 
 def quant_nonlin(x: np.ndarray, bounds: np.ndarray) -> np.ndarray:

@@ -1,0 +1,134 @@
+"""Monte-Carlo driver on the GPU against the oracle's frame-by-frame loop: device sampler, sim_batch,
+the C++ LDPC_BER_Sim_LUT (ber_sim) end to end, results file."""
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import lut_ldpc_amd as L
+from helpers import CODES, ROOT, TREES, oracle_codec
+from itfile_reader import itload
+from oracle import oracle as orc
+from test_host_design_parity import product_codec
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_sampler_matches_oracle():
+    ocd = oracle_codec("n500_q4_i8")
+    pcd = product_codec("n500_q4_i8", device=0)
+    for snr, seed, stream, f0, B in [(1.5, 3, 0, 0, 300), (4.0, 2 ** 40 + 5, 7, 2 ** 33, 17)]:
+        want_cha, want_msg, _ = ocd.sample_labels(snr, 0.5, seed, stream, f0, B)
+        got_cha, got_msg, _ = pcd.sample_labels(snr, seed, stream, f0, B)
+        assert (want_cha == got_cha).all() and (want_msg == got_msg).all()
+    pcd.close()
+
+
+def _oracle_for(pcd, min_lut=True, mode=0):
+    """Oracle codec on the product's (possibly column-permuted) graph with the product's tables."""
+    dv, dc, cn = pcd.graph()
+    code = orc.Code(graph=(pcd.nvar, pcd.nchk, dv, dc, cn))
+    oc = orc.Codec(code, skip_rank=True)
+    oc.set_rank(pcd.rank)
+    return code, oc
+
+
+@pytest.mark.parametrize("zero_codeword", [True, False])
+def test_sim_batch_matches_oracle_frame_loop(zero_codeword):
+    I = 10
+    pcd = L.Codec(CODES / "rate0.50_dv02-17_dc08-09_lut_q4_N500.alist", with_generator=not zero_codeword, device=0)
+    pcd.design_luts(sigma2=0.88 ** 2, max_iters=I)
+    pcd.set_exit_conditions(I, True, True)
+    code, oc = _oracle_for(pcd)
+    oc.set_trees_txt(pcd.var_trees_txt, "", I, np.zeros(I, np.uint8), 16, np.full(I, 16, np.int32), True)
+    oc.set_exit_conditions(I, True, True)
+    # the oracle needs the boundaries for its own cell table: design them on its side (same ensemble)
+    ref = orc.Codec(code, skip_rank=True); ref.design_luts(sigma2=0.88 ** 2, max_iters=I)
+    assert ref.var_tree_txt == pcd.var_trees_txt
+    snr, seed, stream, B = 1.8, 12, 2, 333
+    cw = None
+    if not zero_codeword:
+        _, _, cw = pcd.sample_labels(snr, seed, stream, 0, B, zero_codeword=False)
+        assert cw.any()
+    want_c, want_per, _ = ref.sim_snr_point(snr, 0.5, pcd.ninfo, seed, stream, B, nfers=10 ** 9, codewords=cw)
+    got = pcd.sim_batch(snr, seed, stream, 0, B, zero_codeword=zero_codeword)
+    assert (got == want_per).all(), np.argwhere(got != want_per)[:5]
+    pcd.close()
+
+
+def _setup_basedir(tmp_path):
+    (tmp_path / "codes").mkdir()
+    (tmp_path / "trees").mkdir()
+    for f in CODES.glob("*N500.alist"):
+        shutil.copy(f, tmp_path / "codes" / f.name)
+    shutil.copy(CODES / "rate0.84_reg_v6c32_N2048.alist", tmp_path / "codes")
+    for f in TREES.glob("*.ini"):
+        shutil.copy(f, tmp_path / "trees" / f.name)
+    return tmp_path
+
+
+def test_ber_sim_irregular_example_matches_oracle(tmp_path):
+    """BASELINE config 1: ber_sim -p params/ber.ini.irregular.example (N500, Nframes=100, SNR 0:.5:4, non-zero codewords)."""
+    from lut_ldpc_amd._capi import lib, check
+    import ctypes as C
+    base = _setup_basedir(tmp_path)
+    params = ROOT / "data" / "params" / "ber.ini.irregular.example"
+    snr = (C.c_double * 32)(); cnt = (C.c_int64 * 160)()
+    n = lib.lutldpc_ber_sim_run(str(params).encode(), str(base).encode(), 0, b"", 0, 1, 1, snr, cnt, 32)
+    check(min(n, 0))
+    assert n == 9 and list(snr[:n]) == [0, .5, 1, 1.5, 2, 2.5, 3, 3.5, 4]
+    got = np.array(cnt[:n * 5]).reshape(n, 5)
+    # the same run, frame by frame, with the oracle decoder on the same code / tables / codewords
+    pcd = L.Codec(CODES / "rate0.50_dv02-17_dc08-09_lut_q4_N500.alist", with_generator=True, device=0)
+    pcd.design_luts(sigma2=0.88 ** 2, max_iters=50)
+    dv, dc, cn = pcd.graph()
+    code = orc.Code(graph=(pcd.nvar, pcd.nchk, dv, dc, cn))
+    ref = orc.Codec(code, skip_rank=True); ref.set_rank(250)
+    ref.design_luts(sigma2=0.88 ** 2, max_iters=50)
+    ref.set_exit_conditions(50, True, True)               # psc AND pisc (src/LDPC_BER_Sim.cpp:500)
+    stop = False
+    for i in range(n):
+        if stop:
+            assert (got[i] == 0).all()                     # padded points (src/LDPC_BER_Sim.cpp:142-149)
+            continue
+        _, _, cw = pcd.sample_labels(snr[i], 0, i, 0, 100, zero_codeword=False)
+        want, _, stop = ref.sim_snr_point(snr[i], 0.5, 250, 0, i, 100, nfers=20, codewords=cw)
+        assert (got[i] == want).all(), (i, got[i], want)
+    assert got[0][0] == 21 and got[0][2] == 21              # at 0 dB every frame fails: stops after Nfers+1 errors
+    # results file: name as README.md:114, readable like scripts/itload.m
+    res = base / "results" / "RES_N500_R0.5_maxIter50_zcw0_frames100_minLUT" / "RES_N500_R0.5_maxIter50_zcw0_frames100_minLUT_rseed0000.it"
+    assert res.exists()
+    it = itload(res)
+    assert (it["sim_Nframes"] == got[:, 0]).all() and (it["sim_data_bit_errors"] == got[:, 3]).all()
+    assert it["ldpc_nvar"][0] == 500 and it["ldpc_nchk"][0] == 250
+    assert (res.parent / "lut_codec.it").exists() and (res.parent / "ber.ini.irregular.example").exists()
+    pcd.close()
+
+
+def test_ber_sim_binary_regular_example(tmp_path):
+    """BASELINE config 5 through the command line: (6,32) code, file trees, 3-bit, QCHA, output_verbosity=1."""
+    base = _setup_basedir(tmp_path)
+    exe = ROOT / "lut_ldpc_amd" / "lib" / "ber_sim"
+    r = subprocess.run([str(exe), "-p", str(ROOT / "data" / "params" / "ber.ini.regular.example"), "-b", str(base), "-s", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Stimuli Pair" in r.stdout and r.stdout.count("SNR = ") >= 1
+    out = list((base / "results").glob("RES_N2048_R0.841309_maxIter8_zcw0_frames20_minLUT/*_rseed0003.it"))     # README.md:239
+    assert len(out) == 1
+    it = itload(out[0])
+    assert len(it["sim_SNRdB"]) == 7 and it["sim_Nframes"][0] > 0
+
+
+def test_python_driver_equals_cpp_driver(tmp_path):
+    from lut_ldpc_amd import ber_sim
+    base = _setup_basedir(tmp_path)
+    params = ROOT / "data" / "params" / "ber.ini.irregular.example"
+    pts, path = ber_sim.run(params, base, seed=1, quiet=True)
+    from lut_ldpc_amd._capi import lib
+    import ctypes as C
+    snr = (C.c_double * 32)(); cnt = (C.c_int64 * 160)()
+    n = lib.lutldpc_ber_sim_run(str(params).encode(), str(base).encode(), 1, b"_cpp", 0, 0, 1, snr, cnt, 32)
+    assert n == len(pts)
+    assert (np.array(cnt[:n * 5]).reshape(n, 5) == np.array([c for _, c in pts])).all()
+    assert path and itload(path)["sim_SNRdB"][1] == 0.5
