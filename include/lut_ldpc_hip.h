@@ -118,6 +118,8 @@ int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int 
  *   K_info      number of leading bits counted as data bits (nvar - rank(H))
  *   frame_stats host [B*4] int32: {lut_decode return value, frame error 0/1, data bit errors,
  *               uncoded (slicer) bit errors over all nvar bits}
+ *   cha_out, bits_out  optional host [B*nvar]: the sampled channel labels and the decided bits
+ *               (for the "Stimuli Pair" dump of src/LDPC_Code_LUT.cpp:228-238); NULL to skip
  */
 typedef struct {
     int32_t n_cells;
@@ -130,7 +132,8 @@ typedef struct {
 } lutldpc_channel_cells;
 
 int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream,
-                              uint64_t frame0, int B, const uint8_t *codewords, int K_info, int32_t *frame_stats);
+                              uint64_t frame0, int B, const uint8_t *codewords, int K_info, int32_t *frame_stats,
+                              uint8_t *cha_out, uint8_t *bits_out);
 
 /* The labels the sampler would produce for those frames (host, frame-major [B*nvar]); for tests. */
 int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream,

@@ -676,7 +676,7 @@ int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int 
 }
 
 int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *cells, uint64_t seed, uint32_t stream, uint64_t frame0, int B,
-                              const uint8_t *codewords, int K_info, int32_t *frame_stats) {
+                              const uint8_t *codewords, int K_info, int32_t *frame_stats, uint8_t *cha_out, uint8_t *bits_out) {
     if (!d || !frame_stats) return fail(LUTLDPC_ERR_ARG, "NULL argument");
     if (d->device < 0) return fail(LUTLDPC_ERR_STATE, "decoder was created without a device (host-only handle)");
     if (B <= 0 || K_info < 0 || K_info > d->nvar) return fail(LUTLDPC_ERR_ARG, "bad B / K_info");
@@ -695,6 +695,22 @@ int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *c
         LAUNCH_CHECK();
     }
     HIP_TRY(hipMemcpyAsync(frame_stats, d->d_stats.p, sizeof(int32_t) * (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
+    if (cha_out || bits_out) {
+        const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+        const size_t n = (size_t)B * N;
+        HIP_TRY(d->d_out_bits.alloc(n));
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
+        if (cha_out) {
+            hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_out_bits.p, B, N);
+            LAUNCH_CHECK();
+            HIP_TRY(hipMemcpyAsync(cha_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
+        }
+        if (bits_out) {
+            hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_hard.p, d->d_out_bits.p, B, N);
+            LAUNCH_CHECK();
+            HIP_TRY(hipMemcpyAsync(bits_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return LUTLDPC_OK;
 }

@@ -309,8 +309,13 @@ void LDPC_BER_Sim_LUT::sim_batch(double snr, int snr_index, int64_t frame0, int 
         }
         cwp = codewords.data();
     }
-    if (lutldpc_decoder_sim_batch(C->device_handle(), &view, seed, (uint32_t)snr_index, (uint64_t)frame0, B, cwp, K, reinterpret_cast<int32_t *>(stats)) != LUTLDPC_OK)
+    // output_verbosity > 0: the reference prints every frame's labels and decided bits (src/LDPC_Code_LUT.cpp:228-238)
+    std::vector<uint8_t> cha_dump, bits_dump;
+    if (decoder_output_verbosity > 0) { cha_dump.resize((size_t)B * N); bits_dump.resize((size_t)B * N); }
+    if (lutldpc_decoder_sim_batch(C->device_handle(), &view, seed, (uint32_t)snr_index, (uint64_t)frame0, B, cwp, K, reinterpret_cast<int32_t *>(stats),
+                                  cha_dump.empty() ? nullptr : cha_dump.data(), bits_dump.empty() ? nullptr : bits_dump.data()) != LUTLDPC_OK)
         throw std::runtime_error(std::string("LDPC_BER_Sim_LUT::sim_snr_point(): ") + lutldpc_last_error());
+    for (int i = 0; i < B && !cha_dump.empty(); i++) C->print_stimuli(&cha_dump[(size_t)i * N], &bits_dump[(size_t)i * N]);
 }
 
 bool LDPC_BER_Sim_LUT::sim_snr_point(double snr, int snr_index) {

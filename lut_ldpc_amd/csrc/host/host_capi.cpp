@@ -180,7 +180,7 @@ int lutldpc_codec_sim_batch(lutldpc_codec *c, double snr_db, uint64_t seed, uint
         const lutldpc_channel_cells view = cells.view();
         std::vector<unsigned char> cw;
         if (!zero_codeword) make_codewords(c, seed, stream, frame0, B, cw);
-        return lutldpc_decoder_sim_batch(c->C->device_handle(), &view, seed, stream, frame0, B, zero_codeword ? nullptr : cw.data(), c->C->get_ninfo(), stats);
+        return lutldpc_decoder_sim_batch(c->C->device_handle(), &view, seed, stream, frame0, B, zero_codeword ? nullptr : cw.data(), c->C->get_ninfo(), stats, nullptr, nullptr);
     });
 }
 

@@ -93,6 +93,8 @@ public:
     int get_ninfo() const { return nvar - nchk_lin_indep; }
     int get_nrof_iterations() const { return max_iters; }
     void set_output_verbosity(int v) { output_verbosity = v; }
+    int get_output_verbosity() const { return output_verbosity; }
+    void print_stimuli(const uint8_t *cha, const uint8_t *bits) const;   // src/LDPC_Code_LUT.cpp:228-238
     void set_initial_message_mode(initial_message_mode_t m) { initial_message_mode = m; }
 
     void save_code(const std::string &filename) const;             // src/LDPC_Code_LUT.cpp:643-697
@@ -124,7 +126,6 @@ protected:
 
 private:
     void drop_device();
-    void print_stimuli(const uint8_t *cha, const uint8_t *bits) const;   // src/LDPC_Code_LUT.cpp:228-238
 
     bool H_defined = false, G_defined = false, LUTs_defined = false, minLUT = false;
     int nvar = 0, nchk = 0, nchk_lin_indep = 0;
