@@ -62,6 +62,7 @@ struct NodeClass {
 struct PassPlan {               // one launch: all degree classes of one pass of one tree set
     PassParams P{};
     int lds_bytes = 0;
+    int out_slots = 0;
     bool lds_tab = true;
     bool valid = false;
 };
@@ -105,6 +106,9 @@ struct lutldpc_decoder {
     int nodes_per_block = 16;
     int nodes_per_wave = 8;     // specialised kernels
     int use_fast = 1;
+    int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
+    int tile() const { return kRowBytes * pack; }       // frames per group
+    int bpad(int B) const { return (B + tile() - 1) / tile() * tile(); }
     // ---- profiling
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int kind; };
@@ -163,7 +167,7 @@ int build_plan(lutldpc_decoder *d, const std::vector<NodeClass> &cls, const std:
     P.n_seg = (int)cls.size();
     P.nodes_per_block = d->nodes_per_block;
     P.E = d->E; P.N = d->nvar;
-    int blk = 0, node_off = 0, max_slots = 0, max_tab = 0;
+    int blk = 0, node_off = 0, max_slots = 0, max_tab = 0, max_out = 1;
     for (size_t i = 0; i < cls.size(); i++) {
         PassSeg &S = P.seg[i];
         S.block_begin = blk;
@@ -177,13 +181,15 @@ int build_plan(lutldpc_decoder *d, const std::vector<NodeClass> &cls, const std:
             S.n_in = pr.n_in; S.n_out = pr.n_out; S.n_slots = pr.n_slots;
             max_slots = std::max(max_slots, pr.n_slots);
             max_tab = std::max(max_tab, (int)pr.tables.size());
+            max_out = std::max(max_out, pr.n_out);
         }
         blk += (S.n_nodes + P.nodes_per_block - 1) / P.nodes_per_block;
         node_off += S.n_nodes;
     }
     P.blocks_per_group = blk;
     P.slots_lds = max_slots;
-    int slots_bytes = max_slots * kWave * 4;
+    plan.out_slots = max_out;
+    int slots_bytes = (max_slots + max_out) * kWave * 4;
     if (slots_bytes > 60 * 1024) return fail(LUTLDPC_ERR_UNSUPPORTED, "node program needs more than 60 KiB of LDS slots");
     plan.lds_tab = (slots_bytes + max_tab) <= 64 * 1024;
     plan.lds_bytes = slots_bytes + (plan.lds_tab ? max_tab : 0);
@@ -273,13 +279,13 @@ int upload_static(lutldpc_decoder *d) {
 }
 
 int ensure_batch(lutldpc_decoder *d, int B) {
-    int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames;
+    int Bpad = d->bpad(B);
     if (Bpad <= d->Bcap) return LUTLDPC_OK;
-    size_t G = (size_t)Bpad / kTileFrames;
-    HIP_TRY(d->d_msgs.alloc(G * (size_t)d->E * kTileFrames));
-    HIP_TRY(d->d_cha_t.alloc(G * (size_t)d->nvar * kTileFrames));
-    HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kTileFrames));
-    HIP_TRY(d->d_hard.alloc(G * (size_t)d->nvar * kTileFrames));
+    size_t G = (size_t)(Bpad / d->tile());
+    HIP_TRY(d->d_msgs.alloc(G * (size_t)d->E * kRowBytes));
+    HIP_TRY(d->d_cha_t.alloc(G * (size_t)d->nvar * kRowBytes));
+    HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kRowBytes));
+    HIP_TRY(d->d_hard.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_state.alloc((size_t)Bpad));
     HIP_TRY(d->d_vfail.alloc((size_t)Bpad));
     HIP_TRY(d->d_iters.alloc((size_t)Bpad));
@@ -291,6 +297,13 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     do {                                                                                            \
         hipError_t e_ = hipGetLastError();                                                          \
         if (e_ != hipSuccess) return fail(LUTLDPC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+// instantiate a launch for the decoder's packing
+#define PACK_DISPATCH(d, ...)                        \
+    do {                                             \
+        if ((d)->pack == 2) { constexpr int PK = 2; __VA_ARGS__; } \
+        else { constexpr int PK = 1; __VA_ARGS__; }  \
     } while (0)
 
 int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value) {
@@ -305,9 +318,9 @@ int launch_syndrome(lutldpc_decoder *d, int G) {
     Timed t(d, LUTLDPC_K_SYNDROME);
     const int cpw = 8;
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
-    hipLaunchKernelGGL(syndrome_bits_kernel, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                        reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                       d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, d->nvar, cpw);
+                       d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, d->nvar, cpw));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -340,10 +353,11 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
     if (d->use_fast && fast && KIND != TT_CHK)
         for (int i = 0; i < P.n_seg; i++) {
             if (!(*fast)[(size_t)i].ok) continue;
-            if (launch_vn_fast<KIND>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->nodes_per_wave, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
+            bool ok = false;
+            PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->nodes_per_wave, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
                                      reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
-                                     d->d_vn_list.p, d->d_vn_ptr.p, d->E, d->nvar))
-                keep[(size_t)i] = 0;
+                                     d->d_vn_list.p, d->d_vn_ptr.p, d->E, d->nvar));
+            if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
     if (any) {
@@ -352,13 +366,13 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
         const int32_t *list = KIND == TT_CHK ? d->d_cn_list.p : d->d_vn_list.p;
         const int32_t *ptr = KIND == TT_CHK ? d->d_cn_ptr.p : d->d_vn_ptr.p;
         if (plan.lds_tab)
-            hipLaunchKernelGGL((tree_pass_kernel<KIND, true>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+            PACK_DISPATCH(d, hipLaunchKernelGGL((tree_pass_kernel<KIND, true, PK>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
                                d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
+                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p, plan.out_slots));
         else
-            hipLaunchKernelGGL((tree_pass_kernel<KIND, false>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+            PACK_DISPATCH(d, hipLaunchKernelGGL((tree_pass_kernel<KIND, false, PK>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
                                d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p);
+                               d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p, plan.out_slots));
     }
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -371,17 +385,19 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     std::vector<char> keep((size_t)P.n_seg, 1);
     bool any = false;
     if (d->use_fast)
-        for (int i = 0; i < P.n_seg; i++)
-            if (launch_cn_fast(d->stream, P.seg[i].deg, P.seg[i].n_nodes, P.seg[i].node_off, G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
+        for (int i = 0; i < P.n_seg; i++) {
+            bool ok = false;
+            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, P.seg[i].node_off, G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
                                reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_list.p,
-                               d->d_cn_ptr.p, d->d_cn_idx.p))
-                keep[(size_t)i] = 0;
+                               d->d_cn_ptr.p, d->d_cn_idx.p));
+            if (ok) keep[(size_t)i] = 0;
+        }
     for (char k : keep) any = any || k;
     if (any) {
         P = filter_params(P, keep);
-        hipLaunchKernelGGL(cn_minsum_generic_kernel, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
+        PACK_DISPATCH(d, hipLaunchKernelGGL(cn_minsum_generic_kernel<PK>, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
                            reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                           d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p);
+                           d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p));
     }
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -391,7 +407,7 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
 // Leaves the decided bits in d_hard (tile layout) and the iteration codes in d_iters.
 int decode_tiles(lutldpc_decoder *d, int B) {
     int rc;
-    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames;
+    const int Bpad = d->bpad(B), G = Bpad / d->tile();
     const int N = d->nvar, E = d->E, I = d->max_iters;
     const int last_set = d->iter_set[(size_t)(I - 1)];
     if (!d->dec_plan[(size_t)last_set].valid)
@@ -400,8 +416,8 @@ int decode_tiles(lutldpc_decoder *d, int B) {
     if (d->pisc) {   // :275-279
         {
             Timed t(d, LUTLDPC_K_LAYOUT);
-            size_t nw = (size_t)G * N * kTileFrames / 4;
-            hipLaunchKernelGGL(hard_from_labels_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, nw, d->Nq_Cha / 2);
+            size_t nw = (size_t)G * N * kRowBytes / 4;
+            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_kernel<PK>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, nw, d->Nq_Cha / 2));
             LAUNCH_CHECK();
         }
         if ((rc = launch_syndrome(d, G))) return rc;
@@ -441,19 +457,19 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
     HIP_TRY(hipSetDevice(d->device));
     int rc = ensure_batch(d, B);
     if (rc) return rc;
-    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames;
+    const int Bpad = d->bpad(B), G = Bpad / d->tile();
     const int N = d->nvar;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
-        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha);
-        hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]);
+        dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha));
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]));
         LAUNCH_CHECK();
     }
     if ((rc = decode_tiles(d, B))) return rc;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p, d_out_bits, B, N);
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p, d_out_bits, B, N));
         LAUNCH_CHECK();
         HIP_TRY(hipMemcpyAsync(d_out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToDevice, d->stream));
     }
@@ -480,7 +496,7 @@ int fill_cells(const lutldpc_channel_cells *c, const lutldpc_decoder *d, Channel
 int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint32_t stream, uint64_t frame0, int B, const uint8_t *codewords_host) {
     int rc = ensure_batch(d, B);
     if (rc) return rc;
-    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+    const int Bpad = d->bpad(B), G = Bpad / d->tile(), N = d->nvar;
     HIP_TRY(d->d_stats.alloc((size_t)Bpad * 4));
     HIP_TRY(hipMemsetAsync(d->d_stats.p, 0, sizeof(int32_t) * (size_t)Bpad * 4, d->stream));
     const uint8_t *cw = nullptr;
@@ -492,15 +508,15 @@ int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint3
     Timed t(d, LUTLDPC_K_FRONTEND);
     const int ppt = 8, npairs = (N + 1) / 2;
     dim3 grid((unsigned)((npairs + 4 * ppt - 1) / (4 * ppt)), (unsigned)G);
-    hipLaunchKernelGGL(sample_labels_kernel, grid, dim3(256), 0, d->stream, C, (uint32_t)seed, (uint32_t)(seed >> 32), stream, frame0, B, N, cw,
-                       d->d_cha_t.p, d->d_msg0_t.p, d->d_stats.p, ppt);
+    PACK_DISPATCH(d, hipLaunchKernelGGL(sample_labels_kernel<PK>, grid, dim3(256), 0, d->stream, C, (uint32_t)seed, (uint32_t)(seed >> 32), stream, frame0, B, N, cw,
+                       d->d_cha_t.p, d->d_msg0_t.p, d->d_stats.p, ppt));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
 
 void make_describe(lutldpc_decoder *d) {
     std::ostringstream o;
-    o << "{\"tile_frames\":" << kTileFrames << ",\"message_bytes\":1,\"vector_bytes_per_lane\":4"
+    o << "{\"tile_frames\":" << d->tile() << ",\"message_bytes\":" << (d->pack == 2 ? "0.5" : "1") << ",\"pack\":" << d->pack << ",\"vector_bytes_per_lane\":4"
       << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"nodes_per_wave\":" << d->nodes_per_wave << ",\"use_fast\":" << d->use_fast
       << ",\"vn_classes\":[";
     for (size_t i = 0; i < d->vclass.size(); i++) {
@@ -584,6 +600,10 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     }
     if (const char *e = getenv("LUTLDPC_NODES_PER_BLOCK")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_block = v; }
     if (const char *e = getenv("LUTLDPC_USE_FAST")) d->use_fast = atoi(e) ? 1 : 0;
+    d->pack = 2;
+    if (Nq_Cha > 16) d->pack = 1;
+    for (int i = 0; i < max_iters; i++) if (Nq_Msg[i] > 16) d->pack = 1;
+    if (const char *e = getenv("LUTLDPC_PACK")) { int v = atoi(e); if (v == 1) d->pack = 1; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave = v; }
     int rc = compile_all(d.get());
     if (rc) return rc;
@@ -688,25 +708,25 @@ int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *c
     if ((rc = decode_tiles(d, B))) return rc;
     {
         Timed t(d, LUTLDPC_K_FRONTEND);
-        const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, rpw = 64;
+        const int Bpad = d->bpad(B), G = Bpad / d->tile(), rpw = 64;
         const int rows = K_info > 0 ? K_info : 1;
-        hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
-                           codewords ? d->d_codewords.p : nullptr, B, d->nvar, K_info, d->d_iters.p, d->d_stats.p, rpw);
+        PACK_DISPATCH(d, hipLaunchKernelGGL(count_errors_kernel<PK>, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+                           codewords ? d->d_codewords.p : nullptr, B, d->nvar, K_info, d->d_iters.p, d->d_stats.p, rpw));
         LAUNCH_CHECK();
     }
     HIP_TRY(hipMemcpyAsync(frame_stats, d->d_stats.p, sizeof(int32_t) * (size_t)B * 4, hipMemcpyDeviceToHost, d->stream));
     if (cha_out || bits_out) {
-        const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+        const int Bpad = d->bpad(B), G = Bpad / d->tile(), N = d->nvar;
         const size_t n = (size_t)B * N;
         HIP_TRY(d->d_out_bits.alloc(n));
-        dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
+        dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
         if (cha_out) {
-            hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_out_bits.p, B, N);
+            PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_out_bits.p, B, N));
             LAUNCH_CHECK();
             HIP_TRY(hipMemcpyAsync(cha_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
         }
         if (bits_out) {
-            hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_hard.p, d->d_out_bits.p, B, N);
+            PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_hard.p, d->d_out_bits.p, B, N));
             LAUNCH_CHECK();
             HIP_TRY(hipMemcpyAsync(bits_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
         }
@@ -725,12 +745,12 @@ int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cell
     if (rc) return rc;
     HIP_TRY(hipSetDevice(d->device));
     if ((rc = sample_tiles(d, C, seed, stream, frame0, B, codewords))) return rc;
-    const int Bpad = (B + kTileFrames - 1) / kTileFrames * kTileFrames, G = Bpad / kTileFrames, N = d->nvar;
+    const int Bpad = d->bpad(B), G = Bpad / d->tile(), N = d->nvar;
     const size_t n = (size_t)B * N;
     HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n));
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)G);
-    hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_in_cha.p, B, N);
-    hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_in_msg.p, B, N);
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
+    PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_in_cha.p, B, N));
+    PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_in_msg.p, B, N));
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(cha, d->d_in_cha.p, n, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipMemcpyAsync(msg0, d->d_in_msg.p, n, hipMemcpyDeviceToHost, d->stream));

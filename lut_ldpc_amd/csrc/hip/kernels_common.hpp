@@ -1,21 +1,29 @@
 // kernels_common.hpp -- device-side conventions shared by all gfx950 kernels.
 //
-// Data layout in HBM ("frame tiles"): a batch of B frames is cut into G = ceil(B/256) groups
-// of 256 frames.  Every per-edge / per-node quantity is stored as one 256-byte row per
-// (group, edge|node):
-//      msgs[g][e][f]   uint8, e = VN-major edge id of the reference (src/LDPC_Code_LUT.cpp:513-521)
-//      cha [g][v][f]   uint8 channel labels,   hard[g][v][f] uint8 decided bits
-// One wavefront (64 lanes) owns one row segment: lane L holds frames 4L..4L+3 of the group
-// packed in one dword, so every global access of a wave is a single fully coalesced 256-byte
-// row and all node/edge indices are wave-uniform (scalar registers, scalar loads).
-// Per-frame state lives in byte arrays indexed [g*256 + f] and is read as the same dwords.
+// Data layout in HBM ("frame tiles"): a batch of B frames is cut into groups of 256*PACK frames.
+// Every per-edge / per-node quantity is stored as one 256-byte row per (group, edge|node):
+//      msgs[g][e][256 B]  e = VN-major edge id of the reference (src/LDPC_Code_LUT.cpp:513-521)
+//      cha [g][v][256 B]  channel labels,   hard[g][v][256 B] decided bits
+// PACK = 1: one byte per (row, frame)   -- any alphabet up to 128 labels, b = 1 byte per message
+// PACK = 2: one NIBBLE per (row, frame) -- alphabets up to 16 labels (the 3- and 4-bit decoders the
+//           toolkit is about), b = 0.5 byte per message: half the HBM traffic of both passes.
+// One wavefront (64 lanes) owns one row: lane L holds frames 4*PACK*L .. 4*PACK*L + 4*PACK-1 of the
+// group in ONE dword.  With PACK = 2 the dword is split into two "halves" of four frames each,
+//      half 0 = low nibbles  of bytes 0..3  -> frames 8L+0..3
+//      half 1 = high nibbles of bytes 0..3  -> frames 8L+4..7
+// so that `x & 0x0F0F0F0F` / `(x >> 4) & 0x0F0F0F0F` yield the same "four frames, one per byte"
+// format as PACK = 1 and all byte-parallel (SWAR) arithmetic is shared.
+// Every global access of a wave is a single fully coalesced 256-byte row and all node / edge
+// indices are wave-uniform (scalar registers, scalar loads).
+// Per-frame state lives in byte arrays indexed by frame; a lane's frames are PACK dwords of them.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace lutldpc {
 
-constexpr int kTileFrames = 256;     // frames per group (= 64 lanes x 4 packed bytes)
+constexpr int kRowBytes = 256;       // bytes per row (= 64 lanes x one dword)
+constexpr int kTileFrames = kRowBytes;   // frames per group when PACK = 1 (kept for the host code)
 constexpr int kWave = 64;
 constexpr int kMaxSeg = 32;          // degree classes handled by one pass launch
 
@@ -49,6 +57,28 @@ struct PassParams {
     PassSeg seg[kMaxSeg];
 };
 
+// ---- packing ------------------------------------------------------------------------------------
+// half h of a row dword as four frames, one per byte
+template <int PACK>
+__device__ __forceinline__ uint32_t unpack_half(uint32_t x, int h) {
+    if constexpr (PACK == 1) return x;
+    else return h ? ((x >> 4) & 0x0F0F0F0Fu) : (x & 0x0F0F0F0Fu);
+}
+template <int PACK>
+__device__ __forceinline__ uint32_t pack_halves(const uint32_t (&r)[PACK]) {
+    if constexpr (PACK == 1) return r[0];
+    else return r[0] | (r[1] << 4);
+}
+// byte mask (0xFF / 0x00 per frame) of the two halves -> mask over the packed dword
+template <int PACK>
+__device__ __forceinline__ uint32_t pack_masks(const uint32_t (&m)[PACK]) {
+    if constexpr (PACK == 1) return m[0];
+    else return (m[0] & 0x0F0F0F0Fu) | (m[1] & 0xF0F0F0F0u);
+}
+// dword index of half h of lane `lane` in group g inside a per-frame byte array
+template <int PACK>
+__device__ __forceinline__ int frame_word(int g, int lane, int h) { return (g * kWave + lane) * PACK + h; }
+
 // ---- SWAR helpers on four packed bytes (all byte values < 128) --------------------------------
 // 0x01 in every byte whose value is <  t   (t wave-uniform, 0 <= t <= 128)
 __device__ __forceinline__ uint32_t swar_lt(uint32_t x, uint32_t t) {
@@ -61,12 +91,39 @@ __device__ __forceinline__ uint32_t swar_zero_mask(uint32_t x) {
     uint32_t z = (~nz >> 7) & 0x01010101u;
     return z * 0xFFu;
 }
-// expand 0x01 flags to 0xFF masks
-__device__ __forceinline__ uint32_t swar_flag_to_mask(uint32_t f) { return f * 0xFFu; }
 // (a & m) | (b & ~m)
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 __device__ __forceinline__ bool wave_all_zero(uint32_t x) { return __ballot(x != 0) == 0ull; }
+
+// per-half "still decoding" byte masks of a lane; returns true when the whole wave is finished
+template <int PACK>
+__device__ __forceinline__ bool load_active(const uint32_t *__restrict__ state_w, int g, int lane, uint32_t (&amask)[PACK]) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int h = 0; h < PACK; h++) { amask[h] = swar_zero_mask(state_w[frame_word<PACK>(g, lane, h)]); any |= amask[h]; }
+    return wave_all_zero(any);
+}
+
+// store `val` into a row dword, keeping the old content for frames that already terminated
+template <int PACK>
+__device__ __forceinline__ void store_blend(uint32_t *p, uint32_t val, uint32_t old, uint32_t smask) {
+    *p = bfi(smask, val, old);
+}
+template <int PACK>
+__device__ __forceinline__ void store_row_masked(uint32_t *p, uint32_t val, uint32_t smask) {
+    if (smask == 0xFFFFFFFFu) *p = val;
+    else if (smask) *p = bfi(smask, val, *p);
+}
+
+template <int PACK>
+__device__ __forceinline__ void flag_frames(uint32_t *__restrict__ vfail_w, int g, int lane, const uint32_t (&fail)[PACK], const uint32_t (&amask)[PACK]) {
+#pragma unroll
+    for (int h = 0; h < PACK; h++) {
+        const uint32_t f = fail[h] & amask[h] & 0x01010101u;
+        if (f) atomicOr(&vfail_w[frame_word<PACK>(g, lane, h)], f);
+    }
+}
 
 // locate the degree class of a block: linear scan over <= kMaxSeg scalar entries
 __device__ __forceinline__ int find_seg(const PassParams &P, int b) {

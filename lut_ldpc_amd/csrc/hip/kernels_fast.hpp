@@ -45,8 +45,8 @@ __device__ __forceinline__ uint32_t swar_min(uint32_t a, uint32_t b) {
 
 // Min-sum check pass.  DMAX: register budget (rows kept per check); the true degree is the
 // wave-uniform runtime value P.deg <= DMAX.  QBITS: log2(Nq_Msg) (Nq a power of two).
-// One wave = one 256-frame row segment; UNR checks are in flight per wave.
-template <int DMAX, int UNR>
+// One wave = one 256-byte row; UNR checks are in flight per wave.
+template <int DMAX, int UNR, int PACK>
 __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ node_list, const int32_t *__restrict__ cn_ptr, const int32_t *__restrict__ cn_idx)
@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     const int g = wave / P.waves_per_group;
     if (g >= P.G) return;
     const int chunk = wave - g * P.waves_per_group;
-    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
-    if (wave_all_zero(amask)) return;
-    uint8_t *base = msgs + (size_t)g * (size_t)P.E * kTileFrames + lane * 4;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
+    const uint32_t smask = pack_masks<PACK>(amask);
+    uint8_t *base = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     const uint32_t nzm1 = (uint32_t)(P.nz - 1);
     const uint32_t magmask = nzm1 * 0x01010101u;
     const int sbit = __builtin_ctz((unsigned)P.nz);              // sign bit position (label >= nz <=> bit set)
-    uint32_t fail = 0;
+    uint32_t fail[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) fail[h] = 0;
 
     for (int i = first; i < last; i += UNR) {
         uint32_t x[UNR][DMAX];
@@ -80,44 +83,49 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
             for (int k = 0; k < DMAX; k++)
                 if (k < deg) {
                     e[u][k] = __builtin_amdgcn_readfirstlane(cn_idx[p0 + k]);
-                    x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kTileFrames);
+                    x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kRowBytes);
                 }
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
-            uint32_t min1 = (uint32_t)P.nz * 0x01010101u, min2 = min1, sp = 0;
-            uint32_t pk[DMAX];                                    // magnitude | negative << 7
+            uint32_t out[DMAX];
+#pragma unroll
+            for (int h = 0; h < PACK; h++) {
+                uint32_t min1 = (uint32_t)P.nz * 0x01010101u, min2 = min1, sp = 0;
+                uint32_t pk[DMAX];                                    // magnitude | negative << 7
+#pragma unroll
+                for (int k = 0; k < DMAX; k++)
+                    if (k < deg) {
+                        const uint32_t xh = unpack_half<PACK>(x[u][k], h);
+                        const uint32_t ng = (~xh >> sbit) & 0x01010101u;         // label < nz
+                        const uint32_t mag = (xh ^ (ng * nzm1)) & magmask;      // nz-1-label | label-nz
+                        sp ^= ng;
+                        const uint32_t lo = swar_min(mag, min1);
+                        const uint32_t hi = mag ^ min1 ^ lo;
+                        min2 = swar_min(min2, hi);
+                        min1 = lo;
+                        pk[k] = mag | (ng << 7);
+                    }
+                if (P.check) fail[h] |= sp;
+#pragma unroll
+                for (int k = 0; k < DMAX; k++)
+                    if (k < deg) {
+                        const uint32_t mag = pk[k] & 0x7F7F7F7Fu, ng = (pk[k] >> 7) & 0x01010101u;
+                        const uint32_t eq = swar_zero_mask(mag ^ min1);            // this edge holds the minimum
+                        const uint32_t m = bfi(eq, min2, min1);
+                        const uint32_t so = sp ^ ng;                                // sign of the extrinsic product
+                        // negative: nz-1-m ; positive: nz+m
+                        const uint32_t r = (m ^ (so * nzm1)) | ((so ^ 0x01010101u) << sbit);
+                        if (PACK == 2 && h == 1) out[k] |= r << 4; else out[k] = r;
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < DMAX; k++)
-                if (k < deg) {
-                    const uint32_t ng = (~x[u][k] >> sbit) & 0x01010101u;       // label < nz
-                    const uint32_t mag = (x[u][k] ^ (ng * nzm1)) & magmask;     // nz-1-label | label-nz
-                    sp ^= ng;
-                    const uint32_t lo = swar_min(mag, min1);
-                    const uint32_t hi = mag ^ min1 ^ lo;
-                    min2 = swar_min(min2, hi);
-                    min1 = lo;
-                    pk[k] = mag | (ng << 7);
-                }
-            if (P.check) fail |= sp;
-#pragma unroll
-            for (int k = 0; k < DMAX; k++)
-                if (k < deg) {
-                    const uint32_t mag = pk[k] & 0x7F7F7F7Fu, ng = (pk[k] >> 7) & 0x01010101u;
-                    const uint32_t eq = swar_zero_mask(mag ^ min1);            // this edge holds the minimum
-                    const uint32_t m = bfi(eq, min2, min1);
-                    const uint32_t so = sp ^ ng;                                // sign of the extrinsic product
-                    // negative: nz-1-m ; positive: nz+m
-                    const uint32_t r = (m ^ (so * nzm1)) | ((so ^ 0x01010101u) << sbit);
-                    *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kTileFrames) = bfi(amask, r, x[u][k]);
-                }
+                if (k < deg) *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, out[k], x[u][k]);
         }
     }
-    if (P.check) {
-        fail &= amask;
-        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
-    }
+    if (P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,7 +222,7 @@ __device__ __forceinline__ void bal_all_nodes(const uint32_t *in, uint32_t *v, c
 // Variable-node (KIND = TT_VAR) / decision (TT_DEC) pass for degree-DV nodes with balanced trees.
 // Tables: slots 0..NI-1 = internal nodes in creation order, slot NI = root.
 // DV == 1 (VAR only): ROOT(CHA), the build's degree-1 extension.
-template <int DV, int KIND, bool CHECK>
+template <int DV, int KIND, bool CHECK, int PACK>
 __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
 {
     constexpr int N = (KIND == TT_DEC) ? DV : DV - 1;          // message leaves
     constexpr int NI = N > 1 ? N - 1 : 0;
+    constexpr int NB = N > 1 ? N : 2;                          // shape used for array sizes when N <= 1
     __shared__ __attribute__((aligned(16))) uint8_t lds_tab[(NI + 1) * kFastTableStride];
     // stage the class tables (canonical order, fixed 256-byte slots)
     for (int t = 0; t <= NI; t++) {
@@ -235,69 +244,75 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     const int g = wave / P.waves_per_group;
     if (g >= P.G) return;
     const int chunk = wave - g * P.waves_per_group;
-    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
-    if (wave_all_zero(amask)) return;
-    uint8_t *mbase = msgs + (size_t)g * (size_t)P.E * kTileFrames + lane * 4;
-    const uint8_t *cbase = cha + (size_t)g * (size_t)P.N * kTileFrames + lane * 4;
-    uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kTileFrames + lane * 4;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
+    const uint32_t smask = pack_masks<PACK>(amask);
+    uint8_t *mbase = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
+    const uint8_t *cbase = cha + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
+    uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
-    const int sh = P.shift_msg;
-    uint32_t fail = 0;
+    const int sh = P.shift_msg, shr = P.tab_shift[NI];
+    uint32_t fail[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) fail[h] = 0;
 
     for (int i = first; i < last; i++) {
         const int v = __builtin_amdgcn_readfirstlane(node_list[P.node_off + i]);
         const int e0 = __builtin_amdgcn_readfirstlane(vn_ptr[v]);
-        uint32_t in[DV + 1];
+        uint32_t raw[DV + 1];
 #pragma unroll
-        for (int k = 0; k < DV; k++) in[k] = *reinterpret_cast<const uint32_t *>(mbase + (size_t)(e0 + k) * kTileFrames);
-        const uint32_t ch = *reinterpret_cast<const uint32_t *>(cbase + (size_t)v * kTileFrames);
-        in[DV] = ch;
-        uint32_t val[(N > 1 ? Bal<(N > 1 ? N : 2)>::S.total : 1)];
-        if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
-        if constexpr (KIND == TT_DEC) {
-            uint32_t top;
-            if constexpr (N > 1) top = val[Bal<N>::S.off[Bal<N>::S.top - N] + N];
-            else top = in[0];
-            const uint32_t r = lut4(lds_tab, NI, top, ch, P.tab_shift[NI]);
-            const uint32_t bit = swar_lt(r, 1u);                        // src/LDPC_Code_LUT.cpp:342
-            uint32_t *hp = reinterpret_cast<uint32_t *>(hbase + (size_t)v * kTileFrames);
-            if (amask == 0xFFFFFFFFu) *hp = bit;
-            else if (amask) *hp = bfi(amask, bit, *hp);
-        } else {
-            uint32_t neg_ref = 0;
+        for (int k = 0; k < DV; k++) raw[k] = *reinterpret_cast<const uint32_t *>(mbase + (size_t)(e0 + k) * kRowBytes);
+        raw[DV] = *reinterpret_cast<const uint32_t *>(cbase + (size_t)v * kRowBytes);
+        uint32_t out[DV], bits[PACK];
 #pragma unroll
-            for (int o = 0; o < DV; o++) {
-                uint32_t r;
-                if constexpr (N == 0) {
-                    // degree 1: the only leaf is the channel label
-                    const uint32_t L = ch;
-                    const uint8_t *tb = lds_tab;
-                    r = (uint32_t)tb[L & 0xFFu] | ((uint32_t)tb[(L >> 8) & 0xFFu] << 8) | ((uint32_t)tb[(L >> 16) & 0xFFu] << 16) | ((uint32_t)tb[L >> 24] << 24);
-                } else {
-                    uint32_t top;
-                    if constexpr (N > 1) top = val[Bal<(N > 1 ? N : 2)>::S.off[Bal<(N > 1 ? N : 2)>::S.top - N] + o];
-                    else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
-                    r = lut4(lds_tab, NI, top, ch, P.tab_shift[NI]);
+        for (int h = 0; h < PACK; h++) {
+            uint32_t in[DV + 1];
+#pragma unroll
+            for (int k = 0; k <= DV; k++) in[k] = unpack_half<PACK>(raw[k], h);
+            const uint32_t ch = in[DV];
+            uint32_t val[(N > 1 ? Bal<NB>::S.total : 1)];
+            if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
+            if constexpr (KIND == TT_DEC) {
+                uint32_t top;
+                if constexpr (N > 1) top = val[Bal<NB>::S.off[Bal<NB>::S.top - N] + N];
+                else top = in[0];
+                bits[h] = swar_lt(lut4(lds_tab, NI, top, ch, shr), 1u);          // src/LDPC_Code_LUT.cpp:342
+            } else {
+                uint32_t neg_ref = 0;
+#pragma unroll
+                for (int o = 0; o < DV; o++) {
+                    uint32_t r;
+                    if constexpr (N == 0) {
+                        // degree 1: the only leaf is the channel label
+                        const uint8_t *tb = lds_tab;
+                        r = (uint32_t)tb[ch & 0xFFu] | ((uint32_t)tb[(ch >> 8) & 0xFFu] << 8) | ((uint32_t)tb[(ch >> 16) & 0xFFu] << 16) | ((uint32_t)tb[ch >> 24] << 24);
+                    } else {
+                        uint32_t top;
+                        if constexpr (N > 1) top = val[Bal<NB>::S.off[Bal<NB>::S.top - N] + o];
+                        else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
+                        r = lut4(lds_tab, NI, top, ch, shr);
+                    }
+                    if (PACK == 2 && h == 1) out[o] |= r << 4; else out[o] = r;
+                    if (CHECK) {
+                        const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
+                        if (o == 0) neg_ref = ng; else fail[h] |= ng ^ neg_ref;
+                    }
                 }
-                *reinterpret_cast<uint32_t *>(mbase + (size_t)(e0 + o) * kTileFrames) = bfi(amask, r, in[o]);
-                if (CHECK) {
-                    const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
-                    if (o == 0) neg_ref = ng; else fail |= ng ^ neg_ref;
-                }
-            }
-            if (CHECK && P.write_hard) {
-                uint32_t *hp = reinterpret_cast<uint32_t *>(hbase + (size_t)v * kTileFrames);
-                if (amask == 0xFFFFFFFFu) *hp = neg_ref;
-                else if (amask) *hp = bfi(amask, neg_ref, *hp);
+                bits[h] = neg_ref;
             }
         }
+        if constexpr (KIND == TT_DEC) {
+            store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes), pack_halves<PACK>(bits), smask);
+        } else {
+#pragma unroll
+            for (int o = 0; o < DV; o++) *reinterpret_cast<uint32_t *>(mbase + (size_t)(e0 + o) * kRowBytes) = bfi(smask, out[o], raw[o]);
+            if (CHECK && P.write_hard)
+                store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes), pack_halves<PACK>(bits), smask);
+        }
     }
-    if (KIND == TT_VAR && CHECK) {
-        fail &= amask;
-        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
-    }
+    if (KIND == TT_VAR && CHECK) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,26 +396,26 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
     return fp;
 }
 
-template <int KIND, bool CHECK, int DV>
+template <int KIND, bool CHECK, int PACK, int DV>
 inline void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
                                uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
     const int waves = P.waves_per_group * P.G;
-    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
+    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
                        tables, list, vn_ptr);
 }
 
-template <int KIND, bool CHECK, int... DVs>
+template <int KIND, bool CHECK, int PACK, int... DVs>
 inline bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
                              uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
     bool done = false;
-    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr), done = true) : false), ...);
+    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr), done = true) : false), ...);
     return done;
 }
 
 constexpr int kFastMaxDeg = 20;
 
 // launch one class; returns false when the degree has no instantiation
-template <int KIND>
+template <int KIND, int PACK>
 inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
                            uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr,
                            int E, int N) {
@@ -408,11 +423,12 @@ inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
     constexpr auto seq = std::make_integer_sequence<int, kFastMaxDeg>{};
-    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
-    return dispatch_vn_fast<KIND, false>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
+    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
+    return dispatch_vn_fast<KIND, false, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
 }
 
 // min-sum: one launch per degree class
+template <int PACK>
 inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int node_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
                            const uint32_t *state_w, uint32_t *vfail_w, const int32_t *list, const int32_t *cn_ptr, const int32_t *cn_idx) {
     if (!is_pow2(nz) || nz > 64 || deg < 1 || deg > 32) return false;
@@ -422,10 +438,10 @@ inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int node_off, in
     P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
     const int waves = P.waves_per_group * G;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (deg <= 4) hipLaunchKernelGGL((cn_minsum_fast_kernel<4, 4>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else if (deg <= 8) hipLaunchKernelGGL((cn_minsum_fast_kernel<8, 2>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else if (deg <= 16) hipLaunchKernelGGL((cn_minsum_fast_kernel<16, 1>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else hipLaunchKernelGGL((cn_minsum_fast_kernel<32, 1>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    if (deg <= 4) hipLaunchKernelGGL((cn_minsum_fast_kernel<4, 4, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else if (deg <= 8) hipLaunchKernelGGL((cn_minsum_fast_kernel<8, 2, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else if (deg <= 16) hipLaunchKernelGGL((cn_minsum_fast_kernel<16, 1, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
+    else hipLaunchKernelGGL((cn_minsum_fast_kernel<32, 1, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
     return true;
 }
 

@@ -55,79 +55,90 @@ __device__ __forceinline__ int cell_of(const ChannelCells &C, uint64_t u) {
     return j;
 }
 
-// Writes cha_t / msg0_t rows (tile layout) for B frames starting at global frame index frame0 and
-// adds the slicer errors of each frame to stats[f][3].  One thread = 4 frames x a run of code-bit
-// pairs.  codewords (frame-major [B][N], may be null = all-zero codeword) holds the sent bits.
+// Writes cha_t / msg0_t rows (row layout) for B frames starting at global frame index frame0 and
+// adds the slicer errors of each frame to stats[f][3].  One thread = 4*PACK frames x a run of
+// code-bit pairs.  codewords (frame-major [B][N], may be null = all-zero codeword): the sent bits.
+template <int PACK>
 __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint64_t frame0,
                                                             int B, int N, const uint8_t *__restrict__ codewords, uint8_t *__restrict__ cha_t,
                                                             uint8_t *__restrict__ msg_t, int32_t *__restrict__ stats, int pairs_per_thread)
 {
+    constexpr int F = 4 * PACK;                                     // frames per lane
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int npairs = (N + 1) / 2;
     int p0 = w * pairs_per_thread, p1 = p0 + pairs_per_thread;
     if (p1 > npairs) p1 = npairs;
-    int unc[4] = {0, 0, 0, 0};
-    for (int p = p0; p < p1; p++) {
-        uint32_t ca[2] = {0, 0}, ms[2] = {0, 0};
+    int unc[F];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int fl = g * kTileFrames + lane * 4 + j;          // frame within the batch
+    for (int j = 0; j < F; j++) unc[j] = 0;
+    for (int p = p0; p < p1; p++) {
+        uint32_t ca[2][PACK], ms[2][PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) { ca[0][h] = ca[1][h] = 0; ms[0][h] = ms[1][h] = 0; }
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            const int fl = (g * kWave + lane) * F + j;              // frame within the batch
             if (fl >= B) continue;                                  // pad frames keep label 0
             const uint64_t f = frame0 + (uint64_t)fl;
             uint32_t c[4] = {(uint32_t)f, (uint32_t)(f >> 32), (uint32_t)p, stream};
             Philox::gen(c, seed_lo, seed_hi);
             const uint64_t u[2] = {((uint64_t)c[1] << 32) | c[0], ((uint64_t)c[3] << 32) | c[2]};
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int v = 2 * p + h;
+            for (int hh = 0; hh < 2; hh++) {
+                const int v = 2 * p + hh;
                 if (v >= N) continue;
-                const int cell = cell_of(C, u[h]);
+                const int cell = cell_of(C, u[hh]);
                 const int bit = codewords ? codewords[(size_t)fl * N + v] : 0;
                 const uint32_t a = bit ? C.cha_m[cell] : C.cha[cell], m = bit ? C.msg_m[cell] : C.msg[cell];
                 const int sl = bit ? (C.neg[cell] ^ 1) : C.neg[cell];     // slicer decision
                 unc[j] += (sl != bit);
-                ca[h] |= a << (8 * j);
-                ms[h] |= m << (8 * j);
+                ca[hh][j / 4] |= a << (8 * (j & 3));
+                ms[hh][j / 4] |= m << (8 * (j & 3));
             }
         }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int v = 2 * p + h;
+        for (int hh = 0; hh < 2; hh++) {
+            const int v = 2 * p + hh;
             if (v >= N) continue;
-            *reinterpret_cast<uint32_t *>(cha_t + ((size_t)g * N + v) * kTileFrames + lane * 4) = ca[h];
-            *reinterpret_cast<uint32_t *>(msg_t + ((size_t)g * N + v) * kTileFrames + lane * 4) = ms[h];
+            *reinterpret_cast<uint32_t *>(cha_t + ((size_t)g * N + v) * kRowBytes + lane * 4) = pack_halves<PACK>(ca[hh]);
+            *reinterpret_cast<uint32_t *>(msg_t + ((size_t)g * N + v) * kRowBytes + lane * 4) = pack_halves<PACK>(ms[hh]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int fl = g * kTileFrames + lane * 4 + j;
+    for (int j = 0; j < F; j++) {
+        const int fl = (g * kWave + lane) * F + j;
         if (fl < B && unc[j]) atomicAdd(&stats[(size_t)fl * 4 + 3], unc[j]);
     }
 }
 
 // stats[f] = {iteration code, frame error, data bit errors, uncoded bit errors}: compares the decided
 // bits of the first K positions with the sent ones (BERC / BLERC of src/LDPC_BER_Sim.cpp:284-286)
+template <int PACK>
 __global__ __launch_bounds__(256) void count_errors_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ codewords, int B, int N, int K,
                                                            const int32_t *__restrict__ iters, int32_t *__restrict__ stats, int rows_per_wave)
 {
+    constexpr int F = 4 * PACK;
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     int v0 = w * rows_per_wave, v1 = v0 + rows_per_wave;
     if (v1 > K) v1 = K;
-    int err[4] = {0, 0, 0, 0};
-    for (int v = v0; v < v1; v++) {
-        const uint32_t h = *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + v) * kTileFrames + lane * 4);
+    int err[F];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int fl = g * kTileFrames + lane * 4 + j;
+    for (int j = 0; j < F; j++) err[j] = 0;
+    for (int v = v0; v < v1; v++) {
+        const uint32_t x = *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + v) * kRowBytes + lane * 4);
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            const int fl = (g * kWave + lane) * F + j;
             const int sent = (codewords && fl < B) ? codewords[(size_t)fl * N + v] : 0;
-            err[j] += (int)((h >> (8 * j)) & 1u) != sent;
+            const uint32_t hw = unpack_half<PACK>(x, j / 4);
+            err[j] += (int)((hw >> (8 * (j & 3))) & 1u) != sent;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int fl = g * kTileFrames + lane * 4 + j;
+    for (int j = 0; j < F; j++) {
+        const int fl = (g * kWave + lane) * F + j;
         if (fl < B && err[j]) { atomicAdd(&stats[(size_t)fl * 4 + 2], err[j]); atomicOr(&stats[(size_t)fl * 4 + 1], 1); }
         if (fl < B && v0 == 0) stats[(size_t)fl * 4 + 0] = iters[fl];
     }

@@ -1,5 +1,6 @@
 // kernels_generic.hpp -- generic (any tree, any degree) node-update kernels and the layout
 // kernels.  These are the correctness baseline every specialised kernel is tested against.
+// All kernels are templated on PACK (1 = byte rows, 2 = nibble rows; kernels_common.hpp).
 #pragma once
 #include "kernels_common.hpp"
 #include "lut_program.hpp"
@@ -10,16 +11,18 @@ namespace lutldpc {
 // Node-program interpreter.  KIND: TT_VAR (variable-node pass, src/LDPC_Code_LUT.cpp:404-414),
 // TT_CHK (CHKTREE check pass, :416-426), TT_DEC (decision pass, :428-434,340-344).
 // One wave per block; the program's value slots live in LDS as [slot][lane] dwords (four
-// frames per dword), so a slot access is a conflict-free ds_read/write_b32.  Tables of the
-// class are staged into LDS when they fit (LDS_TAB), else read through L1/L2.
+// frames per dword), so a slot access is a conflict-free ds_read/write_b32.  With nibble rows the
+// program runs once per half and the first half's outputs wait in LDS.  Tables of the class are
+// staged into LDS when they fit (LDS_TAB), else read through L1/L2.
+// LDS: [slots_lds][64] value slots | [n_out_max][64] staged outputs (PACK = 2) | tables
 // ------------------------------------------------------------------------------------------
-template <int KIND, bool LDS_TAB>
+template <int KIND, bool LDS_TAB, int PACK>
 __global__ __launch_bounds__(64) void tree_pass_kernel(
     PassParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const Op *__restrict__ ops,
     const uint8_t *__restrict__ tables, const int32_t *__restrict__ node_list,
     const int32_t *__restrict__ node_ptr,   // VAR/DEC: first edge of each VN ; CHK: offset of each CN in cn_idx
-    const int32_t *__restrict__ cn_idx)
+    const int32_t *__restrict__ cn_idx, int out_slots)
 {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
@@ -28,14 +31,15 @@ __global__ __launch_bounds__(64) void tree_pass_kernel(
     const int si = find_seg(P, b);
     const PassSeg S = P.seg[si];
 
-    const uint32_t st = state_w[g * kWave + lane];
-    const uint32_t amask = swar_zero_mask(st);              // 0xFF for frames still decoding
-    if (wave_all_zero(amask)) return;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
+    const uint32_t smask = pack_masks<PACK>(amask);
 
-    uint32_t *slot = lds;                                    // [n_slots][64]
+    uint32_t *slot = lds;                                    // [slots_lds][64]
+    uint32_t *ostage = lds + P.slots_lds * kWave;            // [out_slots][64]
     const uint8_t *tab;
     if (LDS_TAB) {
-        uint32_t *lt = lds + P.slots_lds * kWave;
+        uint32_t *lt = ostage + out_slots * kWave;
         const uint32_t *gt = reinterpret_cast<const uint32_t *>(tables + S.tab_off);
         for (int i = lane; i < S.tab_bytes / 4; i += kWave) lt[i] = gt[i];
         __syncthreads();
@@ -49,89 +53,92 @@ __global__ __launch_bounds__(64) void tree_pass_kernel(
     int last = first + P.nodes_per_block;
     if (last > S.n_nodes) last = S.n_nodes;
     const Op *prog = ops + S.op_off;
-    uint32_t fail = 0;
+    uint32_t fail[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) fail[h] = 0;
 
     for (int i = first; i < last; i++) {
         const int node = node_list[S.node_off + i];
         const int p0 = node_ptr[node];
-        // ---- gather inputs into slots 0..n_in-1
-        if (KIND == TT_CHK) {
-            uint32_t par = 0;
-            for (int k = 0; k < S.deg; k++) {
-                const int e = cn_idx[p0 + k];
-                const uint32_t x = *reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)e) * kTileFrames + lane * 4);
-                slot[k * kWave + lane] = x;
-                par ^= swar_lt(x, (uint32_t)P.nz);
+        uint32_t neg_ref[PACK], dec_bit[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) {
+            // ---- gather inputs of this half into slots 0..n_in-1
+            if (KIND == TT_CHK) {
+                uint32_t par = 0;
+                for (int k = 0; k < S.deg; k++) {
+                    const int e = cn_idx[p0 + k];
+                    const uint32_t x = unpack_half<PACK>(*reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)e) * kRowBytes + lane * 4), h);
+                    slot[k * kWave + lane] = x;
+                    par ^= swar_lt(x, (uint32_t)P.nz);
+                }
+                if (P.check) fail[h] |= par;
+            } else {
+                for (int k = 0; k < S.deg; k++)
+                    slot[k * kWave + lane] = unpack_half<PACK>(*reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)(p0 + k)) * kRowBytes + lane * 4), h);
+                slot[S.deg * kWave + lane] = unpack_half<PACK>(*reinterpret_cast<const uint32_t *>(cha + (gN + (size_t)node) * kRowBytes + lane * 4), h);
             }
-            if (P.check) fail |= par;
+            // ---- run the program
+            uint32_t have_ref = 0;
+            neg_ref[h] = 0; dec_bit[h] = 0;
+            for (int o = 0; o < S.n_ops; o++) {
+                const Op &op = prog[o];
+                uint32_t lab[4] = {0, 0, 0, 0}, par[4] = {0, 0, 0, 0};
+                for (int c = 0; c < op.nchild; c++) {
+                    const uint32_t x = slot[op.child[c] * kWave + lane];
+                    const uint32_t m = op.mult[c];
+                    if (op.kind == 1) {
+                        const uint32_t hh = op.childK[c] >> 1;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t v = (x >> (8 * j)) & 0xFFu;
+                            const bool ng = v < hh;
+                            par[j] ^= ng ? 1u : 0u;
+                            lab[j] += m * (ng ? (hh - 1 - v) : (v - hh));
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) lab[j] += m * ((x >> (8 * j)) & 0xFFu);
+                    }
+                }
+                uint32_t r = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t idx = lab[j];
+                    if (op.kind == 1 && !par[j]) idx += op.half_len;
+                    if (idx >= op.tab_len) idx = op.tab_len - 1;          // memory safety on corrupt labels
+                    r |= (uint32_t)tab[op.tab_off + idx] << (8 * j);
+                }
+                slot[op.dst * kWave + lane] = r;
+                if (op.out_idx >= 0) {
+                    if (KIND == TT_DEC) dec_bit[h] = swar_lt(r, 1u);       // bit = (label < 1), src/LDPC_Code_LUT.cpp:342
+                    else {
+                        ostage[op.out_idx * kWave + lane] = (PACK == 2 && h == 1) ? (ostage[op.out_idx * kWave + lane] | (r << 4)) : r;
+                        if (KIND == TT_VAR && (P.check || P.write_hard)) {
+                            const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
+                            if (!have_ref) { neg_ref[h] = ng; have_ref = 1; }
+                            else fail[h] |= ng ^ neg_ref[h];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- write back (in place; frames that already terminated keep their old value)
+        if (KIND == TT_DEC) {
+            store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + (gN + (size_t)node) * kRowBytes + lane * 4), pack_halves<PACK>(dec_bit), smask);
         } else {
-            for (int k = 0; k < S.deg; k++)
-                slot[k * kWave + lane] = *reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)(p0 + k)) * kTileFrames + lane * 4);
-            slot[S.deg * kWave + lane] = *reinterpret_cast<const uint32_t *>(cha + (gN + (size_t)node) * kTileFrames + lane * 4);
-        }
-        // ---- run the program
-        uint32_t neg_ref = 0, have_ref = 0;
-        for (int o = 0; o < S.n_ops; o++) {
-            const Op &op = prog[o];
-            uint32_t lab[4] = {0, 0, 0, 0}, par[4] = {0, 0, 0, 0};
-            for (int c = 0; c < op.nchild; c++) {
-                const uint32_t x = slot[op.child[c] * kWave + lane];
-                const uint32_t m = op.mult[c];
-                if (op.kind == 1) {
-                    const uint32_t h = op.childK[c] >> 1;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t v = (x >> (8 * j)) & 0xFFu;
-                        const bool ng = v < h;
-                        par[j] ^= ng ? 1u : 0u;
-                        lab[j] += m * (ng ? (h - 1 - v) : (v - h));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) lab[j] += m * ((x >> (8 * j)) & 0xFFu);
-                }
+            for (int k = 0; k < S.n_out; k++) {
+                size_t row;
+                if (KIND == TT_CHK) row = gE + (size_t)cn_idx[p0 + k];
+                else row = gE + (size_t)(p0 + k);
+                uint32_t *p = reinterpret_cast<uint32_t *>(msgs + row * kRowBytes + lane * 4);
+                store_row_masked<PACK>(p, ostage[k * kWave + lane], smask);
             }
-            uint32_t r = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t idx = lab[j];
-                if (op.kind == 1 && !par[j]) idx += op.half_len;
-                if (idx >= op.tab_len) idx = op.tab_len - 1;          // memory safety on corrupt labels
-                r |= (uint32_t)tab[op.tab_off + idx] << (8 * j);
-            }
-            slot[op.dst * kWave + lane] = r;
-            if (op.out_idx >= 0) {
-                if (KIND == TT_DEC) {
-                    // bit = (label < 1), src/LDPC_Code_LUT.cpp:342
-                    const uint32_t bit = swar_lt(r, 1u);
-                    uint8_t *hp = hard + (gN + (size_t)node) * kTileFrames + lane * 4;
-                    if (amask == 0xFFFFFFFFu) *reinterpret_cast<uint32_t *>(hp) = bit;
-                    else if (amask) *reinterpret_cast<uint32_t *>(hp) = bfi(amask, bit, *reinterpret_cast<uint32_t *>(hp));
-                } else {
-                    // in-place update; frames that already terminated keep their old message
-                    size_t row;
-                    if (KIND == TT_CHK) row = gE + (size_t)cn_idx[p0 + op.out_idx];
-                    else row = gE + (size_t)(p0 + op.out_idx);
-                    const uint32_t old = slot[op.out_idx * kWave + lane];
-                    *reinterpret_cast<uint32_t *>(msgs + row * kTileFrames + lane * 4) = bfi(amask, r, old);
-                    if (KIND == TT_VAR && (P.check || P.write_hard)) {
-                        const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
-                        if (!have_ref) { neg_ref = ng; have_ref = 1; }
-                        else fail |= ng ^ neg_ref;
-                    }
-                }
-            }
-        }
-        if (KIND == TT_VAR && P.write_hard) {
-            uint8_t *hp = hard + (gN + (size_t)node) * kTileFrames + lane * 4;
-            if (amask == 0xFFFFFFFFu) *reinterpret_cast<uint32_t *>(hp) = neg_ref;
-            else if (amask) *reinterpret_cast<uint32_t *>(hp) = bfi(amask, neg_ref, *reinterpret_cast<uint32_t *>(hp));
+            if (KIND == TT_VAR && P.write_hard)
+                store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + (gN + (size_t)node) * kRowBytes + lane * 4), pack_halves<PACK>(neg_ref), smask);
         }
     }
-    if (KIND != TT_DEC && P.check) {
-        fail &= amask;
-        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
-    }
+    if (KIND != TT_DEC && P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(64) void tree_pass_kernel(
 // out magnitude for edge k is min over the others = (mag_k == min1 ? min2 : min1): when the
 // minimum occurs twice min2 == min1, so the reference's min_idx bookkeeping is not needed.
 // ------------------------------------------------------------------------------------------
+template <int PACK>
 __global__ __launch_bounds__(64) void cn_minsum_generic_kernel(
     PassParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ node_list, const int32_t *__restrict__ cn_ptr, const int32_t *__restrict__ cn_idx)
@@ -150,144 +158,183 @@ __global__ __launch_bounds__(64) void cn_minsum_generic_kernel(
     const int g = blockIdx.x / P.blocks_per_group;
     const int b = blockIdx.x - g * P.blocks_per_group;
     const PassSeg S = P.seg[find_seg(P, b)];
-    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
-    if (wave_all_zero(amask)) return;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
+    const uint32_t smask = pack_masks<PACK>(amask);
     const size_t gE = (size_t)g * (size_t)P.E;
     const int first = (b - S.block_begin) * P.nodes_per_block;
     int last = first + P.nodes_per_block;
     if (last > S.n_nodes) last = S.n_nodes;
     const int nz = P.nz;
-    uint32_t fail = 0;
+    uint32_t fail[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) fail[h] = 0;
     for (int i = first; i < last; i++) {
         const int c = node_list[S.node_off + i];
         const int p0 = cn_ptr[c];
-        int min1[4], min2[4];
-        uint32_t sp = 0;
+        int min1[PACK][4], min2[PACK][4];
+        uint32_t sp[PACK];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { min1[j] = nz; min2[j] = nz; }
+        for (int h = 0; h < PACK; h++) {
+            sp[h] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { min1[h][j] = nz; min2[h][j] = nz; }
+        }
         for (int k = 0; k < S.deg; k++) {
-            const uint32_t x = *reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)cn_idx[p0 + k]) * kTileFrames + lane * 4);
+            const uint32_t xr = *reinterpret_cast<const uint32_t *>(msgs + (gE + (size_t)cn_idx[p0 + k]) * kRowBytes + lane * 4);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = (int)((x >> (8 * j)) & 0xFFu);
-                int t;
-                if (v < nz) { sp ^= 1u << (8 * j); t = nz - 1 - v; } else t = v - nz;
-                if (t < min1[j]) { min2[j] = min1[j]; min1[j] = t; }
-                else if (t < min2[j]) min2[j] = t;
+            for (int h = 0; h < PACK; h++) {
+                const uint32_t x = unpack_half<PACK>(xr, h);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int v = (int)((x >> (8 * j)) & 0xFFu);
+                    int t;
+                    if (v < nz) { sp[h] ^= 1u << (8 * j); t = nz - 1 - v; } else t = v - nz;
+                    if (t < min1[h][j]) { min2[h][j] = min1[h][j]; min1[h][j] = t; }
+                    else if (t < min2[h][j]) min2[h][j] = t;
+                }
             }
         }
-        if (P.check) fail |= sp;
-        for (int k = 0; k < S.deg; k++) {
-            uint32_t *row = reinterpret_cast<uint32_t *>(msgs + (gE + (size_t)cn_idx[p0 + k]) * kTileFrames + lane * 4);
-            const uint32_t x = *row;
-            uint32_t r = 0;
+        if (P.check) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = (int)((x >> (8 * j)) & 0xFFu);
-                const bool ng = v < nz;
-                const int t = ng ? nz - 1 - v : v - nz;
-                const int m = (t == min1[j]) ? min2[j] : min1[j];
-                const uint32_t s = ((sp >> (8 * j)) & 1u) ^ (ng ? 1u : 0u);
-                const int o = s ? nz - 1 - m : nz + m;
-                r |= (uint32_t)(o & 0xFF) << (8 * j);
+            for (int h = 0; h < PACK; h++) fail[h] |= sp[h];
+        }
+        for (int k = 0; k < S.deg; k++) {
+            uint32_t *row = reinterpret_cast<uint32_t *>(msgs + (gE + (size_t)cn_idx[p0 + k]) * kRowBytes + lane * 4);
+            const uint32_t xr = *row;
+            uint32_t rr[PACK];
+#pragma unroll
+            for (int h = 0; h < PACK; h++) {
+                const uint32_t x = unpack_half<PACK>(xr, h);
+                uint32_t r = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int v = (int)((x >> (8 * j)) & 0xFFu);
+                    const bool ng = v < nz;
+                    const int t = ng ? nz - 1 - v : v - nz;
+                    const int m = (t == min1[h][j]) ? min2[h][j] : min1[h][j];
+                    const uint32_t s = ((sp[h] >> (8 * j)) & 1u) ^ (ng ? 1u : 0u);
+                    const int o = s ? nz - 1 - m : nz + m;
+                    r |= (uint32_t)(o & (PACK == 2 ? 0x0F : 0xFF)) << (8 * j);
+                }
+                rr[h] = r;
             }
-            *row = bfi(amask, r, x);
+            *row = bfi(smask, pack_halves<PACK>(rr), xr);
         }
     }
-    if (P.check) {
-        fail &= amask;
-        if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
-    }
+    if (P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
 // Layout kernels
 // ------------------------------------------------------------------------------------------
-// frame-major [B][N] -> tiles [G][N][256]; labels are clamped to < limit, pad frames get 0.
+// frame-major [B][N] -> rows [G][N][256 B]; labels are clamped to < limit, pad frames get 0.
+template <int PACK>
 __global__ __launch_bounds__(256) void transpose_in_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                            int B, int N, int limit)
 {
-    __shared__ uint8_t tile[kTileFrames][64 + 4];
-    const int g = blockIdx.y, n0 = blockIdx.x * 64, t = threadIdx.x;
-    const int nn = t & 63, fq = t >> 6;
-    for (int f = fq; f < kTileFrames; f += 4) {
-        const int fr = g * kTileFrames + f, n = n0 + nn;
+    constexpr int F = kRowBytes * PACK;                     // frames per group
+    __shared__ uint8_t tile[F][32 + 4];
+    const int g = blockIdx.y, n0 = blockIdx.x * 32, t = threadIdx.x;
+    const int nn = t & 31, fq = t >> 5;
+    for (int f = fq; f < F; f += 8) {
+        const int fr = g * F + f, n = n0 + nn;
         uint8_t v = 0;
         if (fr < B && n < N) { v = src[(size_t)fr * N + n]; if (v >= limit) v = (uint8_t)(limit - 1); }
         tile[f][nn] = v;
     }
     __syncthreads();
     const int lane = t & 63;
-    for (int r = t >> 6; r < 64; r += 4) {
+    for (int r = t >> 6; r < 32; r += 4) {
         const int n = n0 + r;
         if (n >= N) break;
-        const uint32_t w = (uint32_t)tile[4 * lane][r] | ((uint32_t)tile[4 * lane + 1][r] << 8) |
-                           ((uint32_t)tile[4 * lane + 2][r] << 16) | ((uint32_t)tile[4 * lane + 3][r] << 24);
-        *reinterpret_cast<uint32_t *>(dst + ((size_t)g * N + n) * kTileFrames + lane * 4) = w;
+        uint32_t w[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) {
+            const int f0 = lane * 4 * PACK + 4 * h;
+            w[h] = (uint32_t)tile[f0][r] | ((uint32_t)tile[f0 + 1][r] << 8) | ((uint32_t)tile[f0 + 2][r] << 16) | ((uint32_t)tile[f0 + 3][r] << 24);
+        }
+        *reinterpret_cast<uint32_t *>(dst + ((size_t)g * N + n) * kRowBytes + lane * 4) = pack_halves<PACK>(w);
     }
 }
 
-// tiles [G][N][256] -> frame-major [B][N]
+// rows [G][N][256 B] -> frame-major [B][N]
+template <int PACK>
 __global__ __launch_bounds__(256) void transpose_out_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int B, int N)
 {
-    __shared__ uint8_t tile[kTileFrames][64 + 4];
-    const int g = blockIdx.y, n0 = blockIdx.x * 64, t = threadIdx.x;
+    constexpr int F = kRowBytes * PACK;
+    __shared__ uint8_t tile[F][32 + 4];
+    const int g = blockIdx.y, n0 = blockIdx.x * 32, t = threadIdx.x;
     const int lane = t & 63;
-    for (int r = t >> 6; r < 64; r += 4) {
+    for (int r = t >> 6; r < 32; r += 4) {
         const int n = n0 + r;
-        uint32_t w = 0;
-        if (n < N) w = *reinterpret_cast<const uint32_t *>(src + ((size_t)g * N + n) * kTileFrames + lane * 4);
-        tile[4 * lane][r] = (uint8_t)w; tile[4 * lane + 1][r] = (uint8_t)(w >> 8);
-        tile[4 * lane + 2][r] = (uint8_t)(w >> 16); tile[4 * lane + 3][r] = (uint8_t)(w >> 24);
+        uint32_t x = 0;
+        if (n < N) x = *reinterpret_cast<const uint32_t *>(src + ((size_t)g * N + n) * kRowBytes + lane * 4);
+#pragma unroll
+        for (int h = 0; h < PACK; h++) {
+            const uint32_t w = unpack_half<PACK>(x, h);
+            const int f0 = lane * 4 * PACK + 4 * h;
+            tile[f0][r] = (uint8_t)w; tile[f0 + 1][r] = (uint8_t)(w >> 8);
+            tile[f0 + 2][r] = (uint8_t)(w >> 16); tile[f0 + 3][r] = (uint8_t)(w >> 24);
+        }
     }
     __syncthreads();
-    const int nn = t & 63, fq = t >> 6;
-    for (int f = fq; f < kTileFrames; f += 4) {
-        const int fr = g * kTileFrames + f, n = n0 + nn;
+    const int nn = t & 31, fq = t >> 5;
+    for (int f = fq; f < F; f += 8) {
+        const int fr = g * F + f, n = n0 + nn;
         if (fr < B && n < N) dst[(size_t)fr * N + n] = tile[f][nn];
     }
 }
 
-// msgs[g][e][:] = msg0[g][v(e)][:]  (src/LDPC_Code_LUT.cpp:284-289); one wave per VN
+// msgs[g][e][:] = msg0[g][v(e)][:]  (src/LDPC_Code_LUT.cpp:284-289); one wave per VN (rows are copied whole)
 __global__ __launch_bounds__(256) void init_edges_kernel(const uint8_t *__restrict__ msg0_t, uint8_t *__restrict__ msgs,
                                                          const int32_t *__restrict__ vn_ptr, int N, int E)
 {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), g = blockIdx.y;
     if (v >= N) return;
-    const uint32_t w = *reinterpret_cast<const uint32_t *>(msg0_t + ((size_t)g * N + v) * kTileFrames + lane * 4);
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(msg0_t + ((size_t)g * N + v) * kRowBytes + lane * 4);
     const int e0 = vn_ptr[v], e1 = vn_ptr[v + 1];
-    for (int e = e0; e < e1; e++) *reinterpret_cast<uint32_t *>(msgs + ((size_t)g * E + e) * kTileFrames + lane * 4) = w;
+    for (int e = e0; e < e1; e++) *reinterpret_cast<uint32_t *>(msgs + ((size_t)g * E + e) * kRowBytes + lane * 4) = w;
 }
 
 // hard[g][v][:] = cha[g][v][:] < nz   (src/LDPC_Code_LUT.cpp:275)
+template <int PACK>
 __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__restrict__ cha_t, uint8_t *__restrict__ hard,
                                                                size_t n_words, int nz)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_words) reinterpret_cast<uint32_t *>(hard)[i] = swar_lt(reinterpret_cast<const uint32_t *>(cha_t)[i], (uint32_t)nz);
+    if (i >= n_words) return;
+    const uint32_t x = reinterpret_cast<const uint32_t *>(cha_t)[i];
+    uint32_t r[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), (uint32_t)nz);
+    reinterpret_cast<uint32_t *>(hard)[i] = pack_halves<PACK>(r);
 }
 
 // parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome
+template <int PACK>
 __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__restrict__ hard, const uint32_t *__restrict__ state_w,
                                                             uint32_t *__restrict__ vfail_w, const int32_t *__restrict__ cn_ptr,
                                                             const int32_t *__restrict__ cn_vn, int M, int N, int checks_per_wave)
 {
     const int lane = threadIdx.x & 63, g = blockIdx.y;
-    const uint32_t amask = swar_zero_mask(state_w[g * kWave + lane]);
-    if (wave_all_zero(amask)) return;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     int c0 = w * checks_per_wave, c1 = c0 + checks_per_wave;
     if (c1 > M) c1 = M;
-    uint32_t fail = 0;
+    uint32_t acc = 0;
     for (int c = c0; c < c1; c++) {
         uint32_t s = 0;
         for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++)
-            s ^= *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + cn_vn[k]) * kTileFrames + lane * 4);
-        fail |= s;
+            s ^= *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + cn_vn[k]) * kRowBytes + lane * 4);
+        acc |= s;
     }
-    fail &= amask & 0x01010101u;
-    if (fail) atomicOr(&vfail_w[g * kWave + lane], fail);
+    uint32_t fail[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(acc, h);
+    flag_frames<PACK>(vfail_w, g, lane, fail, amask);
 }
 
 // per-frame state machine between passes

@@ -24,6 +24,8 @@ CONFIGS = {
     "reg36_n1000_mixed": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.82 ** 2, max_iters=12, nq_cha=16,
                                                            nq_msg=[16, 16, 16, 8, 8, 8, 8, 8, 8, 8, 8, 8],
                                                            reuse_vec=[0, 1, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0])),
+    # 5-bit labels: more than 16 labels -> byte rows (PACK = 1), 1024-entry tables -> generic kernels
+    "reg36_n1000_q5": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.84 ** 2, max_iters=8, nq_cha=32, nq_msg=32)),
     "reg36_n1000_q3_chklut": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.80 ** 2, max_iters=10, nq_cha=16, nq_msg=8, min_lut=False)),
     "reg36_n1000_rootonly": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.85 ** 2, max_iters=6, nq_cha=8, nq_msg=8, tree_method="root_only")),
     "reg36_n1000_high": ("rate0.50_dv03_dc06_N1000", dict(sigma2=0.85 ** 2, max_iters=6, nq_cha=16, nq_msg=16, tree_method="auto_bin_high")),

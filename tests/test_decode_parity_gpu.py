@@ -25,6 +25,7 @@ CASES = [
     ("n500_q4", 70, 1.8),                  # C1: irregular dv{2,3,9,17}, mix of converging and failing frames
     ("reg36_n1000_q4", 300, 1.6),          # ragged batch > one 256-frame tile
     ("reg36_n1000_mixed", 64, 2.2),        # non-uniform Nq_Msg + reuse_lut
+    ("reg36_n1000_q5", 40, 1.9),           # 32 labels: byte rows
     ("reg36_n1000_q3_chklut", 40, 2.5),    # CHKTREE check update (min_lut = false)
     ("reg36_n1000_rootonly", 33, 2.5),     # 3-input root tables
     ("reg36_n1000_high", 33, 2.0),
@@ -50,7 +51,24 @@ def test_lut_decode_matches_oracle(name, B, snr, psc, pisc):
     dec.close()
 
 
-@pytest.mark.parametrize("B", [1, 3, 255, 256, 257])
+@pytest.mark.parametrize("name,B,snr", [("n500_q4", 300, 1.8), ("reg36_n1000_mixed", 64, 2.2), ("c5_chklut", 20, 4.2), ("reg36_n1000_high", 33, 2.0)])
+@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_PACK": "1", "LUTLDPC_USE_FAST": "0"}])
+def test_kernel_variants(name, B, snr, env, monkeypatch):
+    """Byte rows vs nibble rows, specialised vs generic kernels: every combination is bit-exact."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    desc = dec.describe()
+    assert desc["pack"] == (1 if "LUTLDPC_PACK" in env else 2) and desc["use_fast"] == (0 if "LUTLDPC_USE_FAST" in env else 1)
+    mode = 1 if name.startswith("c5") else 0
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=77, mode=mode)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 255, 256, 257, 511, 512, 513])
 def test_batch_sizes(B):
     cd = oracle_codec("n500_q4_i8")
     dec = product_decoder(cd)
