@@ -177,11 +177,11 @@ def main():
     vn, cn = prof["vn_pass"], prof["cn_pass"]
     vn_ms = vn["ms"] / max(vn["launches"], 1) or float("nan")
     cn_ms = cn["ms"] / max(cn["launches"], 1) or float("nan")
-    b_msg = 1                                           # bytes per stored edge message (uint8)
-    vn_bytes = (2 * E * b_msg + N) * B                  # read E, write E, read cha (N)
+    b_msg = float(dec.describe()["message_bytes"])      # bytes per stored label: 1 (byte rows) or 0.5 (nibble rows)
+    vn_bytes = (2 * E + N) * b_msg * B                  # read E, write E, read cha (N)
     cn_bytes = 2 * E * b_msg * B
     if psc:
-        vn_bytes += N * B                               # hard-decision rows written for the syndrome test
+        vn_bytes += N * b_msg * B                       # hard-decision rows written for the syndrome test
     it_exec = float(out_iters.abs().float().mean().item())
     # HBM bytes per pass from the PMC counters (collected in separate rocprofv3 --pmc passes and
     # committed under profiles/; valid only for the workload/batch/mode they were taken on)
@@ -208,8 +208,9 @@ def main():
         "roofline_cn_pass": {"bound": "hbm", "achieved": cn_bytes / (cn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": cn_bytes / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": cn_bytes,
                              "avg_launch_ms": cn_ms, "launches": cn["launches"]},
-        "roofline_whole_decode": {"algorithmic_bytes_per_frame": 4 * I * E * b_msg + (I + 2) * N + N / 8,
-                                  "achieved_GBps": (4 * I * E * b_msg + (I + 2) * N + N / 8) * value / world / 1e9},
+        "roofline_whole_decode": {"algorithmic_bytes_per_frame": (4 * I * E + (I + 2) * N) * b_msg + N / 8,
+                                  "achieved_GBps": ((4 * I * E + (I + 2) * N) * b_msg + N / 8) * value / world / 1e9,
+                                  "bytes_per_label": b_msg},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
         "decode_ms_per_step_host_clock": t_decode / args.steps * 1e3,
         "counters": {"frames": int(counters[0]), "data_bits": int(counters[1]), "frame_errors": int(counters[2]),

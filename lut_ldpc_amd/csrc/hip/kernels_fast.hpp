@@ -36,16 +36,18 @@ struct FastParams {
 };
 
 // ------------------------------------------------------------------------------------------
-// SWAR byte minimum for values < 128
-__device__ __forceinline__ uint32_t swar_min(uint32_t a, uint32_t b) {
-    const uint32_t d = (a | 0x80808080u) - b;                    // bit7 of each byte: a >= b
-    const uint32_t m = ((d >> 7) & 0x01010101u) * 0xFFu;
-    return bfi(m, b, a);
-}
-
 // Min-sum check pass.  DMAX: register budget (rows kept per check); the true degree is the
-// wave-uniform runtime value P.deg <= DMAX.  QBITS: log2(Nq_Msg) (Nq a power of two).
-// One wave = one 256-byte row; UNR checks are in flight per wave.
+// wave-uniform runtime value P.deg <= DMAX.  One wave = one 256-byte row; UNR checks are in flight.
+//
+// Byte-parallel arithmetic on four frames per register, full-rate integer ops only.  With
+// nz = Nq/2 = 1 << sbit a label is  [sign bit `sbit` (1 = positive LLR)] [magnitude code in the bits
+// below]: positive -> magnitude = label & LOW, negative -> magnitude = ~label & LOW (this IS the
+// reference's label-nz / nz-1-label, src/LDPC_Code_LUT.cpp:368-374).  Magnitudes never use bit
+// `sbit`, so it serves as the per-byte flag bit of every comparison:
+//      (a | SB) - b  has bit sbit set  <=>  a >= b           (no borrow between bytes)
+//      flag - (flag >> sbit)           =    LOW in flagged bytes (a select mask for magnitudes)
+// min1/min2 start at LOW (= nz-1, the largest magnitude) instead of the reference's nz: identical for
+// every check of degree >= 2 (both are replaced by real magnitudes after two inputs).
 template <int DMAX, int UNR, int PACK>
 __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
@@ -64,9 +66,9 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
     const int deg = P.deg;
-    const uint32_t nzm1 = (uint32_t)(P.nz - 1);
-    const uint32_t magmask = nzm1 * 0x01010101u;
-    const int sbit = __builtin_ctz((unsigned)P.nz);              // sign bit position (label >= nz <=> bit set)
+    const int sbit = __builtin_ctz((unsigned)P.nz);
+    const uint32_t SB = (uint32_t)P.nz * 0x01010101u, LOW = SB - 0x01010101u, ONE = 0x01010101u;
+    const uint32_t odd = (deg & 1) ? SB : 0u;
     uint32_t fail[PACK];
 #pragma unroll
     for (int h = 0; h < PACK; h++) fail[h] = 0;
@@ -92,31 +94,39 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
             uint32_t out[DMAX];
 #pragma unroll
             for (int h = 0; h < PACK; h++) {
-                uint32_t min1 = (uint32_t)P.nz * 0x01010101u, min2 = min1, sp = 0;
-                uint32_t pk[DMAX];                                    // magnitude | negative << 7
+                uint32_t min1 = LOW, min2 = LOW, spp = 0;
+                uint32_t pk[DMAX];                                    // magnitude | positive flag (bit sbit)
 #pragma unroll
                 for (int k = 0; k < DMAX; k++)
                     if (k < deg) {
                         const uint32_t xh = unpack_half<PACK>(x[u][k], h);
-                        const uint32_t ng = (~xh >> sbit) & 0x01010101u;         // label < nz
-                        const uint32_t mag = (xh ^ (ng * nzm1)) & magmask;      // nz-1-label | label-nz
-                        sp ^= ng;
-                        const uint32_t lo = swar_min(mag, min1);
+                        const uint32_t pos = xh & SB;
+                        const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
+                        const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
+                        spp ^= pos;
+                        const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
+                        const uint32_t k1 = g1 - (g1 >> sbit);
+                        const uint32_t lo = bfi(k1, min1, mag);
                         const uint32_t hi = mag ^ min1 ^ lo;
-                        min2 = swar_min(min2, hi);
+                        const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
+                        const uint32_t k2 = g2 - (g2 >> sbit);
+                        min2 = bfi(k2, hi, min2);
                         min1 = lo;
-                        pk[k] = mag | (ng << 7);
+                        pk[k] = mag | pos;
                     }
-                if (P.check) fail[h] |= sp;
+                const uint32_t tn = spp ^ odd;                                    // parity of the negative inputs (bit sbit)
+                if (P.check) fail[h] |= tn >> sbit;
 #pragma unroll
                 for (int k = 0; k < DMAX; k++)
                     if (k < deg) {
-                        const uint32_t mag = pk[k] & 0x7F7F7F7Fu, ng = (pk[k] >> 7) & 0x01010101u;
-                        const uint32_t eq = swar_zero_mask(mag ^ min1);            // this edge holds the minimum
-                        const uint32_t m = bfi(eq, min2, min1);
-                        const uint32_t so = sp ^ ng;                                // sign of the extrinsic product
-                        // negative: nz-1-m ; positive: nz+m
-                        const uint32_t r = (m ^ (so * nzm1)) | ((so ^ 0x01010101u) << sbit);
+                        const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
+                        const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
+                        const uint32_t ke = eq - (eq >> sbit);
+                        const uint32_t m = bfi(ke, min2, min1);
+                        const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
+                        const uint32_t nf = po ^ SB;
+                        const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
+                        const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
                         if (PACK == 2 && h == 1) out[k] |= r << 4; else out[k] = r;
                     }
             }
@@ -193,19 +203,22 @@ __device__ __forceinline__ uint32_t lut4(const uint8_t *lds_tab, int t, uint32_t
 
 // value of child `c` of the balanced tree in variant kc (the first kc leaves of the subtree read
 // the queue unshifted, the others read one element further: the removed message lies before them)
+// (all shape look-ups go through constexpr LOCALS so that they fold to immediates; reading the
+// static member through a reference would be a run-time load in device code)
 template <int N, int C, int KC>
 __device__ __forceinline__ uint32_t bal_child(const uint32_t *in, const uint32_t *v) {
-    constexpr auto &S = Bal<N>::S;
-    if constexpr (C < N) return in[S.first[C] + (KC ? 0 : 1)];
-    else return v[S.off[C - N] + KC];
+    constexpr BalShape<N> S = make_bal_shape<N>();
+    if constexpr (C < N) { constexpr int idx = S.first[C] + (KC ? 0 : 1); return in[idx]; }
+    else { constexpr int idx = S.off[C - N] + KC; return v[idx]; }
 }
 
 template <int N, int J, int K>
 __device__ __forceinline__ void bal_node_variant(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh) {
-    constexpr auto &S = Bal<N>::S;
+    constexpr BalShape<N> S = make_bal_shape<N>();
     constexpr int L = S.left[J], R = S.right[J], sl = S.size[L];
     constexpr int kl = K < sl ? K : sl, kr = K > sl ? K - sl : 0;
-    v[S.off[J] + K] = lut4(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
+    constexpr int dst = S.off[J] + K;
+    v[dst] = lut4(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
 }
 
 template <int N, int J, int... Ks>
@@ -215,8 +228,8 @@ __device__ __forceinline__ void bal_node_all(const uint32_t *in, uint32_t *v, co
 // VAR: all variants of every node; DEC (ALL = false): only the unshifted variant K = size
 template <int N, bool ALL, int... Js>
 __device__ __forceinline__ void bal_all_nodes(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Js...>) {
-    if constexpr (ALL) (bal_node_all<N, Js>(in, v, tab, sh, std::make_integer_sequence<int, Bal<N>::S.size[N + Js] + 1>{}), ...);
-    else (bal_node_variant<N, Js, Bal<N>::S.size[N + Js]>(in, v, tab, sh), ...);
+    if constexpr (ALL) (bal_node_all<N, Js>(in, v, tab, sh, std::make_integer_sequence<int, make_bal_shape<N>().size[N + Js] + 1>{}), ...);
+    else (bal_node_variant<N, Js, make_bal_shape<N>().size[N + Js]>(in, v, tab, sh), ...);
 }
 
 // Variable-node (KIND = TT_VAR) / decision (TT_DEC) pass for degree-DV nodes with balanced trees.
@@ -233,9 +246,11 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     constexpr int NB = N > 1 ? N : 2;                          // shape used for array sizes when N <= 1
     __shared__ __attribute__((aligned(16))) uint8_t lds_tab[(NI + 1) * kFastTableStride];
     // stage the class tables (canonical order, fixed 256-byte slots)
+    // (table offsets and lengths are multiples of 4: lut_program.hpp pads every table)
     for (int t = 0; t <= NI; t++) {
-        const uint8_t *src = tables + P.tab_off[t];
-        for (int i = threadIdx.x; i < P.tab_len[t]; i += 256) lds_tab[t * kFastTableStride + i] = src[i];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[t]);
+        const int i = threadIdx.x;
+        if (i < P.tab_len[t] / 4) reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = src[i];
     }
     __syncthreads();
 
@@ -272,11 +287,13 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
 #pragma unroll
             for (int k = 0; k <= DV; k++) in[k] = unpack_half<PACK>(raw[k], h);
             const uint32_t ch = in[DV];
-            uint32_t val[(N > 1 ? Bal<NB>::S.total : 1)];
+            constexpr BalShape<NB> SH = make_bal_shape<NB>();
+            constexpr int top_off = SH.off[SH.top - NB];
+            uint32_t val[(N > 1 ? SH.total : 1)];
             if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
             if constexpr (KIND == TT_DEC) {
                 uint32_t top;
-                if constexpr (N > 1) top = val[Bal<NB>::S.off[Bal<NB>::S.top - N] + N];
+                if constexpr (N > 1) top = val[top_off + N];
                 else top = in[0];
                 bits[h] = swar_lt(lut4(lds_tab, NI, top, ch, shr), 1u);          // src/LDPC_Code_LUT.cpp:342
             } else {
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
                         r = (uint32_t)tb[ch & 0xFFu] | ((uint32_t)tb[(ch >> 8) & 0xFFu] << 8) | ((uint32_t)tb[(ch >> 16) & 0xFFu] << 16) | ((uint32_t)tb[ch >> 24] << 24);
                     } else {
                         uint32_t top;
-                        if constexpr (N > 1) top = val[Bal<NB>::S.off[Bal<NB>::S.top - N] + o];
+                        if constexpr (N > 1) top = val[top_off + o];
                         else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
                         r = lut4(lds_tab, NI, top, ch, shr);
                     }
