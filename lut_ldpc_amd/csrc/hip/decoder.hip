@@ -86,10 +86,14 @@ struct lutldpc_decoder {
     std::vector<PassPlan> var_plan, chk_plan, dec_plan;   // per tree set
     PassPlan cn_minsum_plan;
     std::vector<std::vector<FastClassPlan>> var_fast, dec_fast;   // [set][class]
+    // dense per-class index tables of the specialised kernels: variable classes {node id, first edge}
+    // per node, check classes the DEG edge ids per node (no pointer chasing, scalar loads)
+    std::vector<int32_t> fast_idx;
+    std::vector<int> vn_idx_off, cn_idx_off;                      // per class
     // ---- device
     int device = -1;
     hipStream_t stream = nullptr;
-    DevBuf<int32_t> d_vn_ptr, d_cn_ptr, d_cn_idx, d_cn_vn, d_vn_list, d_cn_list;
+    DevBuf<int32_t> d_vn_ptr, d_cn_ptr, d_cn_idx, d_cn_vn, d_vn_list, d_cn_list, d_fast_idx;
     DevBuf<Op> d_ops;
     DevBuf<uint8_t> d_tables;
     // batch buffers
@@ -197,8 +201,22 @@ int build_plan(lutldpc_decoder *d, const std::vector<NodeClass> &cls, const std:
     return LUTLDPC_OK;
 }
 
+void build_fast_index(lutldpc_decoder *d) {
+    d->fast_idx.clear(); d->vn_idx_off.clear(); d->cn_idx_off.clear();
+    for (auto &c : d->vclass) {
+        d->vn_idx_off.push_back((int)d->fast_idx.size());
+        for (int v : c.nodes) { d->fast_idx.push_back(v); d->fast_idx.push_back(d->vn_ptr[(size_t)v]); }
+    }
+    for (auto &c : d->cclass) {
+        d->cn_idx_off.push_back((int)d->fast_idx.size());
+        for (int cn : c.nodes)
+            for (int k = 0; k < c.deg; k++) d->fast_idx.push_back(d->cn_msg_idx[(size_t)(d->cn_ptr[(size_t)cn] + k)]);
+    }
+}
+
 int compile_all(lutldpc_decoder *d) {
     std::string err;
+    build_fast_index(d);
     // match trees to degree classes like set_trees (src/LDPC_Code_LUT.cpp:133-139,152-158):
     // VARTREE leaves == dv, CHKTREE leaves + 1 == dc, matched on tree set 0
     if (d->var_trees.empty()) return fail(LUTLDPC_ERR_ARG, "no variable-node trees");
@@ -238,6 +256,7 @@ int compile_all(lutldpc_decoder *d) {
                 std::map<const TreeNode *, std::pair<uint32_t, uint32_t>> tab_of;
                 for (auto &nt : progs[i].node_tabs) tab_of[nt.first] = {(uint32_t)tab_off[i] + nt.second[0], nt.second[1]};
                 (*fast)[i] = plan_fast_vn(t, kind, cls[i].deg, tab_of, node_off, (int)cls[i].nodes.size());
+                (*fast)[i].P.idx_off = d->vn_idx_off[i];
             }
             node_off += (int)cls[i].nodes.size();
         }
@@ -269,6 +288,7 @@ int upload_static(lutldpc_decoder *d) {
     HIP_TRY(d->d_cn_vn.upload(d->cn_vn));
     HIP_TRY(d->d_vn_list.upload(d->vn_list));
     HIP_TRY(d->d_cn_list.upload(d->cn_list));
+    HIP_TRY(d->d_fast_idx.upload(d->fast_idx));
     HIP_TRY(d->d_ops.upload(d->all_ops));
     {   // pad the table blob so that dword staging never reads past the end
         std::vector<uint8_t> t = d->all_tables;
@@ -356,7 +376,7 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
             bool ok = false;
             PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->nodes_per_wave, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
                                      reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
-                                     d->d_vn_list.p, d->d_vn_ptr.p, d->E, d->nvar));
+                                     d->d_fast_idx.p, d->E, d->nvar));
             if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
@@ -387,9 +407,8 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     if (d->use_fast)
         for (int i = 0; i < P.n_seg; i++) {
             bool ok = false;
-            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, P.seg[i].node_off, G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
-                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_list.p,
-                               d->d_cn_ptr.p, d->d_cn_idx.p));
+            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
+                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p));
             if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
@@ -526,7 +545,7 @@ void make_describe(lutldpc_decoder *d) {
     }
     o << "],\"cn_classes\":[";
     for (size_t i = 0; i < d->cclass.size(); i++) {
-        const bool f = d->use_fast && d->min_lut && d->cclass[i].deg <= 32 && is_pow2(d->Nq_Msg[0] / 2);
+        const bool f = d->use_fast && d->min_lut && d->cclass[i].deg >= 2 && d->cclass[i].deg <= kFastMaxCnDeg && is_pow2(d->Nq_Msg[0] / 2);
         o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size() << ",\"kernel\":\""
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel") : "tree_pass_kernel<CHK>") << "\"}";
     }
@@ -621,7 +640,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (auto &e : d->ev_live) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : d->ev_pool) (void)hipEventDestroy(e);
-        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release();
+        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();

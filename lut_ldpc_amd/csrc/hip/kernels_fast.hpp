@@ -24,6 +24,7 @@ constexpr int kFastTableStride = 256;  // bytes per table slot in LDS
 
 struct FastParams {
     int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
+    int32_t idx_off;       // offset of the class in the dense index blob (see decoder.hip: build_fast_index)
     int32_t G, E, N;
     int32_t nz;            // sign threshold (see PassParams)
     int32_t shift_msg;     // log2 of the message alphabet feeding the tables (label = a | b << shift)
@@ -48,13 +49,15 @@ struct FastParams {
 //      flag - (flag >> sbit)           =    LOW in flagged bytes (a select mask for magnitudes)
 // min1/min2 start at LOW (= nz-1, the largest magnitude) instead of the reference's nz: identical for
 // every check of degree >= 2 (both are replaced by real magnitudes after two inputs).
-template <int DMAX, int UNR, int PACK>
+// DEG is the exact check degree (straight-line code, all row loads of UNR checks issued up front);
+// `edges` is the dense [n_nodes][DEG] table of edge ids of this degree class, read with scalar loads.
+template <int DEG, int UNR, int PACK>
 __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
-    const int32_t *__restrict__ node_list, const int32_t *__restrict__ cn_ptr, const int32_t *__restrict__ cn_idx)
+    const int32_t *__restrict__ fast_idx)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
     const int g = wave / P.waves_per_group;
     if (g >= P.G) return;
     const int chunk = wave - g * P.waves_per_group;
@@ -62,77 +65,72 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
     uint8_t *base = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
+    const int32_t *edges = fast_idx + P.idx_off;
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
-    const int deg = P.deg;
     const int sbit = __builtin_ctz((unsigned)P.nz);
     const uint32_t SB = (uint32_t)P.nz * 0x01010101u, LOW = SB - 0x01010101u, ONE = 0x01010101u;
-    const uint32_t odd = (deg & 1) ? SB : 0u;
+    const uint32_t odd = (DEG & 1) ? SB : 0u;
     uint32_t fail[PACK];
 #pragma unroll
     for (int h = 0; h < PACK; h++) fail[h] = 0;
 
     for (int i = first; i < last; i += UNR) {
-        uint32_t x[UNR][DMAX];
-        int e[UNR][DMAX];
+        uint32_t x[UNR][DEG];
+        int e[UNR][DEG];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int ii = (i + u < last) ? i + u : last - 1;
-            const int c = __builtin_amdgcn_readfirstlane(node_list[P.node_off + ii]);
-            const int p0 = __builtin_amdgcn_readfirstlane(cn_ptr[c]);
 #pragma unroll
-            for (int k = 0; k < DMAX; k++)
-                if (k < deg) {
-                    e[u][k] = __builtin_amdgcn_readfirstlane(cn_idx[p0 + k]);
-                    x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kRowBytes);
-                }
+            for (int k = 0; k < DEG; k++) e[u][k] = edges[(size_t)ii * DEG + k];
         }
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+            for (int k = 0; k < DEG; k++) x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kRowBytes);
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
-            uint32_t out[DMAX];
+            uint32_t out[DEG];
 #pragma unroll
             for (int h = 0; h < PACK; h++) {
                 uint32_t min1 = LOW, min2 = LOW, spp = 0;
-                uint32_t pk[DMAX];                                    // magnitude | positive flag (bit sbit)
+                uint32_t pk[DEG];                                     // magnitude | positive flag (bit sbit)
 #pragma unroll
-                for (int k = 0; k < DMAX; k++)
-                    if (k < deg) {
-                        const uint32_t xh = unpack_half<PACK>(x[u][k], h);
-                        const uint32_t pos = xh & SB;
-                        const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
-                        const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
-                        spp ^= pos;
-                        const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
-                        const uint32_t k1 = g1 - (g1 >> sbit);
-                        const uint32_t lo = bfi(k1, min1, mag);
-                        const uint32_t hi = mag ^ min1 ^ lo;
-                        const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
-                        const uint32_t k2 = g2 - (g2 >> sbit);
-                        min2 = bfi(k2, hi, min2);
-                        min1 = lo;
-                        pk[k] = mag | pos;
-                    }
+                for (int k = 0; k < DEG; k++) {
+                    const uint32_t xh = unpack_half<PACK>(x[u][k], h);
+                    const uint32_t pos = xh & SB;
+                    const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
+                    const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
+                    spp ^= pos;
+                    const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
+                    const uint32_t k1 = g1 - (g1 >> sbit);
+                    const uint32_t lo = bfi(k1, min1, mag);
+                    const uint32_t hi = mag ^ min1 ^ lo;
+                    const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
+                    const uint32_t k2 = g2 - (g2 >> sbit);
+                    min2 = bfi(k2, hi, min2);
+                    min1 = lo;
+                    pk[k] = mag | pos;
+                }
                 const uint32_t tn = spp ^ odd;                                    // parity of the negative inputs (bit sbit)
                 if (P.check) fail[h] |= tn >> sbit;
 #pragma unroll
-                for (int k = 0; k < DMAX; k++)
-                    if (k < deg) {
-                        const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
-                        const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
-                        const uint32_t ke = eq - (eq >> sbit);
-                        const uint32_t m = bfi(ke, min2, min1);
-                        const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
-                        const uint32_t nf = po ^ SB;
-                        const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
-                        const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
-                        if (PACK == 2 && h == 1) out[k] |= r << 4; else out[k] = r;
-                    }
+                for (int k = 0; k < DEG; k++) {
+                    const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
+                    const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
+                    const uint32_t ke = eq - (eq >> sbit);
+                    const uint32_t m = bfi(ke, min2, min1);
+                    const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
+                    const uint32_t nf = po ^ SB;
+                    const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
+                    const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
+                    if (PACK == 2 && h == 1) out[k] |= r << 4; else out[k] = r;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < DMAX; k++)
-                if (k < deg) *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, out[k], x[u][k]);
+            for (int k = 0; k < DEG; k++) *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, out[k], x[u][k]);
         }
     }
     if (P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
@@ -239,7 +237,7 @@ template <int DV, int KIND, bool CHECK, int PACK>
 __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
-    const int32_t *__restrict__ node_list, const int32_t *__restrict__ vn_ptr)
+    const int32_t *__restrict__ fast_idx)
 {
     constexpr int N = (KIND == TT_DEC) ? DV : DV - 1;          // message leaves
     constexpr int NI = N > 1 ? N - 1 : 0;
@@ -255,13 +253,14 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
     const int g = wave / P.waves_per_group;
     if (g >= P.G) return;
     const int chunk = wave - g * P.waves_per_group;
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
+    const int32_t *vtab = fast_idx + P.idx_off;                 // dense [n_nodes][2] = {node id, first edge}
     uint8_t *mbase = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
     const uint8_t *cbase = cha + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
     uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
@@ -274,8 +273,7 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     for (int h = 0; h < PACK; h++) fail[h] = 0;
 
     for (int i = first; i < last; i++) {
-        const int v = __builtin_amdgcn_readfirstlane(node_list[P.node_off + i]);
-        const int e0 = __builtin_amdgcn_readfirstlane(vn_ptr[v]);
+        const int v = vtab[2 * (size_t)i], e0 = vtab[2 * (size_t)i + 1];
         uint32_t raw[DV + 1];
 #pragma unroll
         for (int k = 0; k < DV; k++) raw[k] = *reinterpret_cast<const uint32_t *>(mbase + (size_t)(e0 + k) * kRowBytes);
@@ -415,51 +413,59 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
 
 template <int KIND, bool CHECK, int PACK, int DV>
 inline void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
-                               uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
+                               uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     const int waves = P.waves_per_group * P.G;
     hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
-                       tables, list, vn_ptr);
+                       tables, fast_idx);
 }
 
 template <int KIND, bool CHECK, int PACK, int... DVs>
 inline bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
-                             uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr) {
+                             uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     bool done = false;
-    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr), done = true) : false), ...);
+    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), done = true) : false), ...);
     return done;
 }
 
-constexpr int kFastMaxDeg = 20;
+constexpr int kFastMaxDeg = 20;      // variable / decision nodes
+constexpr int kFastMaxCnDeg = 32;    // check nodes
 
 // launch one class; returns false when the degree has no instantiation
 template <int KIND, int PACK>
 inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
-                           uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *list, const int32_t *vn_ptr,
-                           int E, int N) {
+                           uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N) {
     P.G = G; P.E = E; P.N = N; P.nz = nz; P.check = check; P.write_hard = write_hard;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
     constexpr auto seq = std::make_integer_sequence<int, kFastMaxDeg>{};
-    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
-    return dispatch_vn_fast<KIND, false, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, list, vn_ptr);
+    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+    return dispatch_vn_fast<KIND, false, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+}
+
+template <int PACK, int DEG>
+inline void launch_cn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+    constexpr int UNR = DEG <= 4 ? 4 : DEG <= 10 ? 2 : 1;
+    const int waves = P.waves_per_group * P.G;
+    hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
+}
+template <int PACK, int... Ds>
+inline bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w,
+                             uint32_t *vfail_w, const int32_t *fast_idx) {
+    bool done = false;
+    ((deg == Ds + 1 ? (launch_cn_fast_one<PACK, Ds + 1>(s, P, msgs, state_w, vfail_w, fast_idx), done = true) : false), ...);
+    return done;
 }
 
 // min-sum: one launch per degree class
 template <int PACK>
-inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int node_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
-                           const uint32_t *state_w, uint32_t *vfail_w, const int32_t *list, const int32_t *cn_ptr, const int32_t *cn_idx) {
-    if (!is_pow2(nz) || nz > 64 || deg < 1 || deg > 32) return false;
+inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
+                           const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+    if (!is_pow2(nz) || nz > 64 || deg < 2 || deg > kFastMaxCnDeg) return false;
     FastParams P{};
-    P.n_nodes = n_nodes; P.node_off = node_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg;
+    P.n_nodes = n_nodes; P.idx_off = idx_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
-    const int waves = P.waves_per_group * G;
-    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (deg <= 4) hipLaunchKernelGGL((cn_minsum_fast_kernel<4, 4, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else if (deg <= 8) hipLaunchKernelGGL((cn_minsum_fast_kernel<8, 2, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else if (deg <= 16) hipLaunchKernelGGL((cn_minsum_fast_kernel<16, 1, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    else hipLaunchKernelGGL((cn_minsum_fast_kernel<32, 1, PACK>), grid, block, 0, s, P, msgs, state_w, vfail_w, list, cn_ptr, cn_idx);
-    return true;
+    return dispatch_cn_fast<PACK>(deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, msgs, state_w, vfail_w, fast_idx);
 }
 
 }  // namespace lutldpc
