@@ -20,7 +20,7 @@
 namespace lutldpc {
 
 constexpr int kFastMaxTables = 32;     // LUT nodes of one balanced tree (degree <= 33)
-constexpr int kFastTableStride = 256;  // bytes per table slot in LDS
+constexpr int kFastTableStride = 128;  // bytes per table slot in LDS (see lut4)
 
 struct FastParams {
     int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
@@ -34,6 +34,7 @@ struct FastParams {
     int32_t tab_off[kFastMaxTables];    // byte offsets into the table blob, canonical node order
     int32_t tab_len[kFastMaxTables];
     int32_t tab_shift[kFastMaxTables];  // log2 alphabet of each table's first child
+    int32_t nib;                        // 1: tables staged as nibbles (two entries per byte), see lut4
 };
 
 // ------------------------------------------------------------------------------------------
@@ -191,12 +192,26 @@ struct Bal {
     static constexpr BalShape<N> S = make_bal_shape<N>();
 };
 
-// one look-up for the four packed frames: label = a | b << sh, table slot `t` in LDS
+// One look-up for the four packed frames: label = a | b << sh, table slot `t` in LDS.
+// A 256-entry byte table would span 64 dwords = every LDS bank twice, and two lanes of a 32-lane
+// group reading different dwords of one bank cost an extra cycle (measured: 51 % of the LDS cycles of
+// the degree-8 kernel were such 2-way conflicts).  Tables whose outputs fit 4 bits are therefore staged
+// as NIBBLES: entry i in byte i>>1, low nibble for even i.  128 bytes = 32 dwords = one dword per bank:
+// every access is conflict-free.  The nibble is selected for all four frames at once (SWAR).
+template <bool NIB>
 __device__ __forceinline__ uint32_t lut4(const uint8_t *lds_tab, int t, uint32_t a, uint32_t b, int sh) {
     const uint32_t L = a | (b << sh);
     const uint8_t *tb = lds_tab + t * kFastTableStride;
-    const uint32_t r0 = tb[L & 0xFFu], r1 = tb[(L >> 8) & 0xFFu], r2 = tb[(L >> 16) & 0xFFu], r3 = tb[L >> 24];
-    return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    if constexpr (NIB) {
+        const uint32_t r0 = tb[(L >> 1) & 0x7Fu], r1 = tb[(L >> 9) & 0x7Fu], r2 = tb[(L >> 17) & 0x7Fu], r3 = tb[L >> 25];
+        const uint32_t R = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+        const uint32_t od = L & 0x01010101u;                    // odd entry -> high nibble
+        const uint32_t M = (od << 4) - od;                      // 0x0F where odd
+        return bfi(M, R >> 4, R) & 0x0F0F0F0Fu;
+    } else {
+        const uint32_t r0 = tb[L & 0xFFu], r1 = tb[(L >> 8) & 0xFFu], r2 = tb[(L >> 16) & 0xFFu], r3 = tb[L >> 24];
+        return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    }
 }
 
 // value of child `c` of the balanced tree in variant kc (the first kc leaves of the subtree read
@@ -210,30 +225,30 @@ __device__ __forceinline__ uint32_t bal_child(const uint32_t *in, const uint32_t
     else { constexpr int idx = S.off[C - N] + KC; return v[idx]; }
 }
 
-template <int N, int J, int K>
+template <int N, int J, int K, bool NIB>
 __device__ __forceinline__ void bal_node_variant(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh) {
     constexpr BalShape<N> S = make_bal_shape<N>();
     constexpr int L = S.left[J], R = S.right[J], sl = S.size[L];
     constexpr int kl = K < sl ? K : sl, kr = K > sl ? K - sl : 0;
     constexpr int dst = S.off[J] + K;
-    v[dst] = lut4(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
+    v[dst] = lut4<NIB>(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
 }
 
-template <int N, int J, int... Ks>
+template <int N, int J, bool NIB, int... Ks>
 __device__ __forceinline__ void bal_node_all(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Ks...>) {
-    (bal_node_variant<N, J, Ks>(in, v, tab, sh), ...);
+    (bal_node_variant<N, J, Ks, NIB>(in, v, tab, sh), ...);
 }
 // VAR: all variants of every node; DEC (ALL = false): only the unshifted variant K = size
-template <int N, bool ALL, int... Js>
+template <int N, bool ALL, bool NIB, int... Js>
 __device__ __forceinline__ void bal_all_nodes(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Js...>) {
-    if constexpr (ALL) (bal_node_all<N, Js>(in, v, tab, sh, std::make_integer_sequence<int, make_bal_shape<N>().size[N + Js] + 1>{}), ...);
-    else (bal_node_variant<N, Js, make_bal_shape<N>().size[N + Js]>(in, v, tab, sh), ...);
+    if constexpr (ALL) (bal_node_all<N, Js, NIB>(in, v, tab, sh, std::make_integer_sequence<int, make_bal_shape<N>().size[N + Js] + 1>{}), ...);
+    else (bal_node_variant<N, Js, make_bal_shape<N>().size[N + Js], NIB>(in, v, tab, sh), ...);
 }
 
 // Variable-node (KIND = TT_VAR) / decision (TT_DEC) pass for degree-DV nodes with balanced trees.
 // Tables: slots 0..NI-1 = internal nodes in creation order, slot NI = root.
 // DV == 1 (VAR only): ROOT(CHA), the build's degree-1 extension.
-template <int DV, int KIND, bool CHECK, int PACK>
+template <int DV, int KIND, bool CHECK, int PACK, bool NIB>
 __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
@@ -248,7 +263,17 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
     for (int t = 0; t <= NI; t++) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[t]);
         const int i = threadIdx.x;
-        if (i < P.tab_len[t] / 4) reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = src[i];
+        if constexpr (NIB) {
+            // 256 byte entries -> 128 bytes of nibbles: thread i packs entries 8i..8i+7 into one dword
+            if (i < P.tab_len[t] / 8) {
+                const uint32_t lo = src[2 * i], hi = src[2 * i + 1];
+                const uint32_t pl = (lo & 0x0Fu) | ((lo >> 4) & 0xF0u) | ((lo >> 8) & 0xF00u) | ((lo >> 12) & 0xF000u);
+                const uint32_t ph = (hi & 0x0Fu) | ((hi >> 4) & 0xF0u) | ((hi >> 8) & 0xF00u) | ((hi >> 12) & 0xF000u);
+                reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = pl | (ph << 16);
+            }
+        } else {
+            if (i < P.tab_len[t] / 4) reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = src[i];
+        }
     }
     __syncthreads();
 
@@ -288,26 +313,25 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
             constexpr BalShape<NB> SH = make_bal_shape<NB>();
             constexpr int top_off = SH.off[SH.top - NB];
             uint32_t val[(N > 1 ? SH.total : 1)];
-            if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
+            if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR, NIB>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
             if constexpr (KIND == TT_DEC) {
                 uint32_t top;
                 if constexpr (N > 1) top = val[top_off + N];
                 else top = in[0];
-                bits[h] = swar_lt(lut4(lds_tab, NI, top, ch, shr), 1u);          // src/LDPC_Code_LUT.cpp:342
+                bits[h] = swar_lt(lut4<NIB>(lds_tab, NI, top, ch, shr), 1u);     // src/LDPC_Code_LUT.cpp:342
             } else {
                 uint32_t neg_ref = 0;
 #pragma unroll
                 for (int o = 0; o < DV; o++) {
                     uint32_t r;
                     if constexpr (N == 0) {
-                        // degree 1: the only leaf is the channel label
-                        const uint8_t *tb = lds_tab;
-                        r = (uint32_t)tb[ch & 0xFFu] | ((uint32_t)tb[(ch >> 8) & 0xFFu] << 8) | ((uint32_t)tb[(ch >> 16) & 0xFFu] << 16) | ((uint32_t)tb[ch >> 24] << 24);
+                        // degree 1: the only leaf is the channel label (a one-input table: label = ch)
+                        r = lut4<NIB>(lds_tab, 0, ch, 0u, 0);
                     } else {
                         uint32_t top;
                         if constexpr (N > 1) top = val[top_off + o];
                         else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
-                        r = lut4(lds_tab, NI, top, ch, shr);
+                        r = lut4<NIB>(lds_tab, NI, top, ch, shr);
                     }
                     if (PACK == 2 && h == 1) out[o] |= r << 4; else out[o] = r;
                     if (CHECK) {
@@ -392,7 +416,7 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
     for (size_t j = 0; j < canon.size(); j++) {
         const TreeNode *nd = canon[j];
         auto it = tab_of.find(nd);
-        if (it == tab_of.end() || it->second.second > (uint32_t)kFastTableStride) return fp;
+        if (it == tab_of.end() || it->second.second > 256u) return fp;
         for (auto &c : nd->child) if (!is_pow2(c->K) || c->K > 128) return fp;
         if (!is_pow2(nd->K) || nd->K > 128) return fp;
         const int sh0 = __builtin_ctz((unsigned)nd->child[0]->K);
@@ -406,6 +430,15 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
     }
     fp.P.shift_msg = shift_msg < 0 ? 0 : shift_msg;
     fp.P.n_tables = (int)canon.size();
+    // byte tables must fit the 128-byte LDS slot; longer ones go in as nibbles, which needs 4-bit outputs
+    // and a length that is a multiple of 8
+    bool need_nib = false, can_nib = true;
+    for (size_t j = 0; j < canon.size(); j++) {
+        if (fp.P.tab_len[j] > kFastTableStride) need_nib = true;
+        if (canon[j]->K > 16 || (fp.P.tab_len[j] & 7)) can_nib = false;
+    }
+    if (need_nib && !can_nib) return fp;
+    fp.P.nib = need_nib ? 1 : 0;
     fp.P.deg = d; fp.P.node_off = node_off; fp.P.n_nodes = n_nodes;
     fp.ok = true;
     return fp;
@@ -415,8 +448,12 @@ template <int KIND, bool CHECK, int PACK, int DV>
 inline void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
                                uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     const int waves = P.waves_per_group * P.G;
-    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
-                       tables, fast_idx);
+    if (P.nib)
+        hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
+                           tables, fast_idx);
+    else
+        hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
+                           tables, fast_idx);
 }
 
 template <int KIND, bool CHECK, int PACK, int... DVs>
