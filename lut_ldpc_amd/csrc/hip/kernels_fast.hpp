@@ -20,7 +20,7 @@
 namespace lutldpc {
 
 constexpr int kFastMaxTables = 32;     // LUT nodes of one balanced tree (degree <= 33)
-constexpr int kFastTableStride = 128;  // bytes per table slot in LDS (see lut4)
+constexpr int kFastTableStride = 256;  // bytes per table slot in LDS (byte tables; nibble tables use the first half)
 
 struct FastParams {
     int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
@@ -430,15 +430,15 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
     }
     fp.P.shift_msg = shift_msg < 0 ? 0 : shift_msg;
     fp.P.n_tables = (int)canon.size();
-    // byte tables must fit the 128-byte LDS slot; longer ones go in as nibbles, which needs 4-bit outputs
-    // and a length that is a multiple of 8
-    bool need_nib = false, can_nib = true;
+    // optional nibble staging of 256-entry tables (conflict-free LDS reads, more VALU; measured SLOWER on
+    // MI355X for the DVB-S2 classes, so off unless LUTLDPC_NIB_TABLES=1): needs 4-bit outputs
+    bool want_nib = false, can_nib = true;
     for (size_t j = 0; j < canon.size(); j++) {
-        if (fp.P.tab_len[j] > kFastTableStride) need_nib = true;
+        if (fp.P.tab_len[j] > 128) want_nib = true;
         if (canon[j]->K > 16 || (fp.P.tab_len[j] & 7)) can_nib = false;
     }
-    if (need_nib && !can_nib) return fp;
-    fp.P.nib = need_nib ? 1 : 0;
+    const char *env = getenv("LUTLDPC_NIB_TABLES");
+    fp.P.nib = (env && atoi(env) == 1 && want_nib && can_nib) ? 1 : 0;
     fp.P.deg = d; fp.P.node_off = node_off; fp.P.n_nodes = n_nodes;
     fp.ok = true;
     return fp;
