@@ -70,12 +70,13 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
+    // SWAR element = one byte (PACK = 1) or one NIBBLE (PACK = 2): with nibble rows the arithmetic runs
+    // on all eight frames of the dword at once, no unpacking (nz <= 8, so sign bit + magnitude fit 4 bits)
+    constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;
     const int sbit = __builtin_ctz((unsigned)P.nz);
-    const uint32_t SB = (uint32_t)P.nz * 0x01010101u, LOW = SB - 0x01010101u, ONE = 0x01010101u;
+    const uint32_t SB = (uint32_t)P.nz * ONE, LOW = SB - ONE;
     const uint32_t odd = (DEG & 1) ? SB : 0u;
-    uint32_t fail[PACK];
-#pragma unroll
-    for (int h = 0; h < PACK; h++) fail[h] = 0;
+    uint32_t failw = 0;
 
     for (int i = first; i < last; i += UNR) {
         uint32_t x[UNR][DEG];
@@ -93,48 +94,47 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
-            uint32_t out[DEG];
+            uint32_t min1 = LOW, min2 = LOW, spp = 0;
+            uint32_t pk[DEG];                                     // magnitude | positive flag (bit sbit)
 #pragma unroll
-            for (int h = 0; h < PACK; h++) {
-                uint32_t min1 = LOW, min2 = LOW, spp = 0;
-                uint32_t pk[DEG];                                     // magnitude | positive flag (bit sbit)
-#pragma unroll
-                for (int k = 0; k < DEG; k++) {
-                    const uint32_t xh = unpack_half<PACK>(x[u][k], h);
-                    const uint32_t pos = xh & SB;
-                    const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
-                    const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
-                    spp ^= pos;
-                    const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
-                    const uint32_t k1 = g1 - (g1 >> sbit);
-                    const uint32_t lo = bfi(k1, min1, mag);
-                    const uint32_t hi = mag ^ min1 ^ lo;
-                    const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
-                    const uint32_t k2 = g2 - (g2 >> sbit);
-                    min2 = bfi(k2, hi, min2);
-                    min1 = lo;
-                    pk[k] = mag | pos;
-                }
-                const uint32_t tn = spp ^ odd;                                    // parity of the negative inputs (bit sbit)
-                if (P.check) fail[h] |= tn >> sbit;
-#pragma unroll
-                for (int k = 0; k < DEG; k++) {
-                    const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
-                    const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
-                    const uint32_t ke = eq - (eq >> sbit);
-                    const uint32_t m = bfi(ke, min2, min1);
-                    const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
-                    const uint32_t nf = po ^ SB;
-                    const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
-                    const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
-                    if (PACK == 2 && h == 1) out[k] |= r << 4; else out[k] = r;
-                }
+            for (int k = 0; k < DEG; k++) {
+                const uint32_t xh = x[u][k];
+                const uint32_t pos = xh & SB;
+                const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
+                const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
+                spp ^= pos;
+                const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
+                const uint32_t k1 = g1 - (g1 >> sbit);
+                const uint32_t lo = bfi(k1, min1, mag);
+                const uint32_t hi = mag ^ min1 ^ lo;
+                const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
+                const uint32_t k2 = g2 - (g2 >> sbit);
+                min2 = bfi(k2, hi, min2);
+                min1 = lo;
+                pk[k] = mag | pos;
             }
+            const uint32_t tn = spp ^ odd;                                    // parity of the negative inputs (bit sbit)
+            if (P.check) failw |= tn >> sbit;
 #pragma unroll
-            for (int k = 0; k < DEG; k++) *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, out[k], x[u][k]);
+            for (int k = 0; k < DEG; k++) {
+                const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
+                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
+                const uint32_t ke = eq - (eq >> sbit);
+                const uint32_t m = bfi(ke, min2, min1);
+                const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
+                const uint32_t nf = po ^ SB;
+                const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
+                const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
+                *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, r, xh);
+            }
         }
     }
-    if (P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    if (P.check) {
+        uint32_t fail[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
+        flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -481,9 +481,14 @@ inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check
 
 template <int PACK, int DEG>
 inline void launch_cn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+    // checks in flight per wave: more = more loads outstanding per wave, fewer = fewer VGPRs = more waves
     constexpr int UNR = DEG <= 4 ? 4 : DEG <= 10 ? 2 : 1;
+    static const int unr_env = getenv("LUTLDPC_CN_UNR") ? atoi(getenv("LUTLDPC_CN_UNR")) : 0;
     const int waves = P.waves_per_group * P.G;
-    hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
+    if (unr_env == 1 || UNR == 1)
+        hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, 1, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
+    else
+        hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
 }
 template <int PACK, int... Ds>
 inline bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w,
