@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
                 const uint32_t nf = po ^ SB;
                 const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
                 const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
-                *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, r, xh);
+                *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, r, x[u][k]);
             }
         }
     }
