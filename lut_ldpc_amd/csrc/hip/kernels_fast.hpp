@@ -437,8 +437,9 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
         if (fp.P.tab_len[j] > 128) want_nib = true;
         if (canon[j]->K > 16 || (fp.P.tab_len[j] & 7)) can_nib = false;
     }
-    const char *env = getenv("LUTLDPC_NIB_TABLES");
-    fp.P.nib = (env && atoi(env) == 1 && want_nib && can_nib) ? 1 : 0;
+    const char *env = getenv("LUTLDPC_NIB_TABLES");          // minimum degree that gets nibble tables (0 = never)
+    const int nib_min_deg = env ? atoi(env) : 0;
+    fp.P.nib = (nib_min_deg > 0 && d >= nib_min_deg && want_nib && can_nib) ? 1 : 0;
     fp.P.deg = d; fp.P.node_off = node_off; fp.P.n_nodes = n_nodes;
     fp.ok = true;
     return fp;
