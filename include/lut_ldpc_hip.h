@@ -150,7 +150,8 @@ void *lutldpc_decoder_stream(lutldpc_decoder *d);
 #define LUTLDPC_K_SYNDROME  3   /* parity checks                                   */
 #define LUTLDPC_K_LAYOUT    4   /* transposes / edge initialisation / state update */
 #define LUTLDPC_K_FRONTEND  5   /* channel sampler + error counting                */
-#define LUTLDPC_K_COUNT     6
+#define LUTLDPC_K_FUSED_PASS 6  /* skewed pipeline: check pass of one half + variable pass of the other */
+#define LUTLDPC_K_COUNT     7
 
 /* When enabled every launch is bracketed by HIP events recorded on the decoder's stream. */
 int lutldpc_decoder_set_profiling(lutldpc_decoder *d, int enable);

@@ -13,8 +13,8 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "liblut_ldpc_amd.so"
 
 OK, ERR_ARG, ERR_PARSE, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = 0, -1, -2, -3, -4, -5
-K_CN_PASS, K_VN_PASS, K_DECISION, K_SYNDROME, K_LAYOUT, K_FRONTEND, K_COUNT = 0, 1, 2, 3, 4, 5, 6
-KIND_NAMES = ["cn_pass", "vn_pass", "decision", "syndrome", "layout", "frontend"]
+K_CN_PASS, K_VN_PASS, K_DECISION, K_SYNDROME, K_LAYOUT, K_FRONTEND, K_FUSED_PASS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+KIND_NAMES = ["cn_pass", "vn_pass", "decision", "syndrome", "layout", "frontend", "fused_pass"]
 
 
 class LutLdpcError(RuntimeError):

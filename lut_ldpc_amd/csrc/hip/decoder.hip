@@ -11,10 +11,13 @@
 #include "kernels_frontend.hpp"
 #include "lut_program.hpp"
 
+namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast_*.hip / fused.hip
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -108,9 +111,20 @@ struct lutldpc_decoder {
     DevBuf<int32_t> d_stats;
     // ---- tuning
     int nodes_per_block = 16;
-    int nodes_per_wave = 8;     // specialised kernels
+    // specialised kernels: nodes handled by one wave = edges_per_wave / degree (equal work per wave for
+    // every degree class); a fixed count when LUTLDPC_NODES_PER_WAVE[_CN] is set.  Measured on MI355X
+    // (DVB-S2, 4096 frames): short waves win -- 4 degree-8 nodes / 8 degree-7 checks per wave.
+    int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
+    int vn_edges_per_wave = 32, cn_edges_per_wave = 56;
+    int fused_prio = 0;
+    double tail_front = 0.15;   // fused launches: fraction of the item list that the slowest role stays clear of at the end
+    int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, vn_edges_per_wave / std::max(deg, 1)); }
+    int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, cn_edges_per_wave / std::max(deg, 1)); }
     int use_fast = 1;
     int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
+    int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (needs G >= 2)
+    bool skew_ok = false;       // every class of every set has a case in the fused kernel
+    std::map<std::vector<int>, std::unique_ptr<DevBuf<int32_t>>> item_tabs;   // role block counts -> interleaved item table
     int tile() const { return kRowBytes * pack; }       // frames per group
     int bpad(int B) const { return (B + tile() - 1) / tile() * tile(); }
     // ---- profiling
@@ -326,10 +340,13 @@ int ensure_batch(lutldpc_decoder *d, int B) {
         else { constexpr int PK = 1; __VA_ARGS__; }  \
     } while (0)
 
-int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value) {
+// frames f0 .. f1-1 (both multiples of 256); default: the whole padded batch
+int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value, int f0 = 0, int f1 = -1) {
     Timed t(d, LUTLDPC_K_LAYOUT);
-    hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(Bpad / 256)), dim3(256), 0, d->stream,
-                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, Bpad, mode, value);
+    if (f1 < 0) f1 = Bpad;
+    if (f1 <= f0) return LUTLDPC_OK;
+    hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)((f1 - f0) / 256)), dim3(256), 0, d->stream,
+                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, f0, f1, mode, value);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -374,7 +391,7 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
         for (int i = 0; i < P.n_seg; i++) {
             if (!(*fast)[(size_t)i].ok) continue;
             bool ok = false;
-            PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->nodes_per_wave, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
+            PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->npw_vn((*fast)[(size_t)i].P.deg), d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
                                      reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
                                      d->d_fast_idx.p, d->E, d->nvar));
             if (ok) keep[(size_t)i] = 0;
@@ -407,7 +424,7 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     if (d->use_fast)
         for (int i = 0; i < P.n_seg; i++) {
             bool ok = false;
-            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->nodes_per_wave, d->d_msgs.p,
+            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->npw_cn(P.seg[i].deg), d->d_msgs.p,
                                reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p));
             if (ok) keep[(size_t)i] = 0;
         }
@@ -419,6 +436,131 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
                            d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p));
     }
     LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+// ----------------------------------------------------------------------------- skewed two-half pipeline
+// (kernels_fast.hpp: pass_fused_kernel).  Half A = groups [0, GA), half B = [GA, G).  Each half runs
+// the reference's sequence  CN(0) VN(0) CN(1) ... CN(I-1)  (src/LDPC_Code_LUT.cpp:301-338); B lags A by
+// one pass, so every launch pairs a check pass of one half with a variable pass of the other.
+struct HalfRange { int g0, G; };
+
+bool skew_eligible(const lutldpc_decoder *d) {
+    if (!d->min_lut || !d->use_fast) return false;
+    if ((int)(d->cclass.size() + d->vclass.size()) > kFusedMaxRoles) return false;
+    for (auto &c : d->cclass) if (c.deg < 2 || c.deg > kFusedMaxCnDeg) return false;
+    for (int nq : d->Nq_Msg) if (!is_pow2(nq / 2) || nq / 2 > 64) return false;
+    for (size_t s = 0; s < d->var_fast.size(); s++) {
+        if (d->var_plan[s].valid == false) continue;          // decision-only set
+        for (auto &f : d->var_fast[s])
+            if (!f.ok || f.P.nib || f.P.deg > kFusedMaxVnDeg || f.P.n_tables > kFusedMaxTables) return false;
+    }
+    return true;
+}
+
+void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int nz, int check) {
+    for (size_t i = 0; i < d->cclass.size(); i++) {
+        RoleParams R{};
+        const int npw = d->npw_cn(d->cclass[i].deg);
+        R.kind = 0; R.deg = d->cclass[i].deg; R.g0 = h.g0; R.G = h.G;
+        R.n_nodes = (int)d->cclass[i].nodes.size(); R.nodes_per_wave = npw;
+        R.waves_per_group = (R.n_nodes + npw - 1) / npw;
+        R.idx_off = d->cn_idx_off[i]; R.E = d->E; R.N = d->nvar; R.nz = nz; R.check = check;
+        FP.role[FP.n_roles++] = R;
+        blocks.push_back((R.waves_per_group * h.G + 3) / 4);
+    }
+}
+void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int set, int nz, int check, int write_hard) {
+    for (size_t i = 0; i < d->vclass.size(); i++) {
+        const FastParams &F = d->var_fast[(size_t)set][i].P;
+        const int npw = d->npw_vn(F.deg);
+        RoleParams R{};
+        R.kind = 1; R.deg = F.deg; R.g0 = h.g0; R.G = h.G;
+        R.n_nodes = F.n_nodes; R.nodes_per_wave = npw;
+        R.waves_per_group = (R.n_nodes + npw - 1) / npw;
+        R.idx_off = F.idx_off; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard;
+        for (int t = 0; t < F.n_tables; t++) { R.tab_off[t] = F.tab_off[t]; R.tab_len[t] = F.tab_len[t]; R.tab_shift[t] = F.tab_shift[t]; }
+        FP.role[FP.n_roles++] = R;
+        blocks.push_back((R.waves_per_group * h.G + 3) / 4);
+    }
+}
+
+// interleave the blocks of all roles evenly over the launch: block j of a role with n blocks sits at
+// position (j + 1/2) / n of the timeline
+int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::vector<double> &front, const int32_t **out, int *total) {
+    int nb = 0;
+    for (int b : blocks) nb += b;
+    *total = nb;
+    auto it = d->item_tabs.find(blocks);
+    if (it == d->item_tabs.end()) {
+        std::vector<std::pair<double, std::pair<int, int>>> pos;
+        pos.reserve((size_t)nb);
+        // `front[r]` in [0,1): roles with long-running blocks are issued over [0, 1 - front) only, so that the
+        // launch does not end on a tail of a few slow blocks (the next launch needs this one complete)
+        for (size_t r = 0; r < blocks.size(); r++)
+            for (int j = 0; j < blocks[r]; j++) pos.push_back({((double)j + 0.5) / (double)blocks[r] * (1.0 - front[r]), {(int)r, j}});
+        std::stable_sort(pos.begin(), pos.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        std::vector<int32_t> h;
+        h.reserve(2 * (size_t)nb);
+        for (auto &q : pos) { h.push_back(q.second.first); h.push_back(q.second.second); }
+        std::unique_ptr<DevBuf<int32_t>> buf(new DevBuf<int32_t>());
+        HIP_TRY(buf->upload(h));
+        it = d->item_tabs.emplace(blocks, std::move(buf)).first;
+    }
+    *out = it->second->p;
+    return LUTLDPC_OK;
+}
+
+int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, bool vn_check) {
+    const int32_t *items = nullptr;
+    int nb = 0, rc;
+    // per-wave work of a role ~ edges per wave, a variable-node edge costing about 3x a check edge (LUT look-ups)
+    std::vector<double> cost(blocks.size()), front(blocks.size());
+    double cmax = 0;
+    for (size_t r = 0; r < blocks.size(); r++) {
+        const RoleParams &R = FP.role[r];
+        cost[r] = (double)R.deg * R.nodes_per_wave * (R.kind ? 3.0 * R.deg / 4.0 : 1.0);
+        cmax = std::max(cmax, cost[r]);
+    }
+    for (size_t r = 0; r < blocks.size(); r++) front[r] = d->tail_front * cost[r] / (cmax > 0 ? cmax : 1.0);
+    if ((rc = item_table(d, blocks, front, &items, &nb))) return rc;
+    if (nb == 0) return LUTLDPC_OK;
+    Timed t(d, LUTLDPC_K_FUSED_PASS);
+    PACK_DISPATCH(d, lutldpc::launch_fused<PK>(d->stream, FP, items, nb, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p),
+                                              reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+// the message-passing iterations of decode_tiles for both halves
+int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
+    const int I = d->max_iters, n_ops = 2 * I - 1;
+    const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
+    const int psc = d->psc ? 1 : 0;
+    int rc;
+    for (int slot = 0; slot <= n_ops; slot++) {
+        FusedParams FP{};
+        FP.prio = d->fused_prio;
+        std::vector<int> blocks;
+        int state_half = -1, state_ii = 0;
+        for (int hf = 0; hf < 2; hf++) {
+            const int op = slot - hf;                 // B lags by one pass
+            if (op < 0 || op >= n_ops) continue;
+            const int ii = op / 2;
+            if ((op & 1) == 0) {                      // CN(ii)
+                const int check = (psc && ii > 0) ? 1 : 0;
+                add_cn_roles(d, FP, blocks, half[hf], d->Nq_Msg[(size_t)ii] / 2, check);
+                if (check) { state_half = hf; state_ii = ii; }
+            } else {                                  // VN(ii)
+                add_vn_roles(d, FP, blocks, half[hf], d->iter_set[(size_t)ii], d->Nq_Msg[(size_t)(ii + 1)] / 2, psc, psc);
+            }
+        }
+        if ((rc = launch_fused_pass(d, FP, blocks, psc != 0))) return rc;
+        if (state_half >= 0) {                        // :327-329 returns (ii-1)+1
+            const int f0 = half[state_half].g0 * d->tile(), f1 = f0 + half[state_half].G * d->tile();
+            if ((rc = launch_state(d, B, Bpad, 2, state_ii, f0, f1))) return rc;
+        }
+    }
     return LUTLDPC_OK;
 }
 
@@ -447,7 +589,9 @@ int decode_tiles(lutldpc_decoder *d, int B) {
         hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
         LAUNCH_CHECK();
     }
-    for (int ii = 0; ii < I; ii++) {   // :301-338
+    const bool skewed = d->skew && d->skew_ok && G >= 2;
+    if (skewed && (rc = iterate_skewed(d, B, Bpad, G))) return rc;
+    for (int ii = 0; ii < I && !skewed; ii++) {   // :301-338
         const int set = d->iter_set[(size_t)ii];
         const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
         const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
@@ -536,7 +680,7 @@ int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint3
 void make_describe(lutldpc_decoder *d) {
     std::ostringstream o;
     o << "{\"tile_frames\":" << d->tile() << ",\"message_bytes\":" << (d->pack == 2 ? "0.5" : "1") << ",\"pack\":" << d->pack << ",\"vector_bytes_per_lane\":4"
-      << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"nodes_per_wave\":" << d->nodes_per_wave << ",\"use_fast\":" << d->use_fast
+      << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"vn_edges_per_wave\":" << d->vn_edges_per_wave << ",\"cn_edges_per_wave\":" << d->cn_edges_per_wave << ",\"use_fast\":" << d->use_fast
       << ",\"vn_classes\":[";
     for (size_t i = 0; i < d->vclass.size(); i++) {
         const bool f = d->use_fast && !d->var_fast.empty() && i < d->var_fast[0].size() && d->var_fast[0][i].ok && d->vclass[i].deg <= kFastMaxDeg;
@@ -549,7 +693,7 @@ void make_describe(lutldpc_decoder *d) {
         o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size() << ",\"kernel\":\""
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel") : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "]}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << "}";
     d->describe = o.str();
 }
 
@@ -606,6 +750,8 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
             d->cn_vn[(size_t)k] = edge_vn[(size_t)e];
         }
     }
+    if ((uint64_t)d->E * kRowBytes >= (1ull << 32) || (uint64_t)nvar * kRowBytes >= (1ull << 32))
+        return fail(LUTLDPC_ERR_UNSUPPORTED, "code too large: the rows of one frame group must stay below 4 GiB");
     build_classes(d->dv, d->vclass, d->vn_list);
     build_classes(d->dc, d->cclass, d->cn_list);
     d->Nq_Cha = Nq_Cha; d->Nq_Msg.assign(Nq_Msg, Nq_Msg + max_iters);
@@ -624,8 +770,16 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     for (int i = 0; i < max_iters; i++) if (Nq_Msg[i] > 16) d->pack = 1;
     if (const char *e = getenv("LUTLDPC_PACK")) { int v = atoi(e); if (v == 1) d->pack = 1; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave = v; }
+    d->nodes_per_wave_cn = d->nodes_per_wave;
+    if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
+    if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE_CN")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave_cn = v; }
+    if (const char *e = getenv("LUTLDPC_SKEW")) d->skew = atoi(e) ? 1 : 0;
     int rc = compile_all(d.get());
     if (rc) return rc;
+    d->skew_ok = skew_eligible(d.get());
     d->device = device;
     if (device >= 0) { rc = upload_static(d.get()); if (rc) return rc; }
     make_describe(d.get());
@@ -643,6 +797,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
+        for (auto &kv : d->item_tabs) kv.second->release();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
     }

@@ -94,6 +94,34 @@ __device__ __forceinline__ uint32_t swar_zero_mask(uint32_t x) {
 // (a & m) | (b & ~m)
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
+// Row access through a buffer resource: the descriptor (4 SGPRs) covers the rows of one frame group,
+// the row offset is wave-uniform (SGPR soffset) and the lane supplies only its byte offset within the
+// row (one VGPR): no 64-bit address arithmetic in vector registers, and an out-of-range row reads 0 /
+// drops the store instead of faulting.  One group's rows must stay below 4 GiB (checked at create).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t ld_row(rsrc_t r, uint32_t row_off, uint32_t lane4) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane4, (int)row_off, 0);
+}
+__device__ __forceinline__ void st_row(rsrc_t r, uint32_t row_off, uint32_t lane4, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)lane4, (int)row_off, 0);
+}
+
+// Entry of a software-pipelined loop whose first step was peeled: drain the vector-memory queue
+// (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched) with scheduling barriers on both sides.  The
+// compiler places its waits per basic block from the merged state of all predecessors; entering the
+// loop with nothing outstanding makes the entry edge agree with the back edge, so that inside the loop
+// the only wait is "prefetched loads done, the stores issued after them still in flight".
+__device__ __forceinline__ void pipeline_entry_fence() {
+    asm volatile("" ::: "memory");          // IR level: no load may sink below the fence
+    __builtin_amdgcn_sched_barrier(0);      // machine scheduler: nothing moves across
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ bool wave_all_zero(uint32_t x) { return __ballot(x != 0) == 0ull; }
 
 // per-half "still decoding" byte masks of a lane; returns true when the whole wave is finished

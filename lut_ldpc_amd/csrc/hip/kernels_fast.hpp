@@ -26,6 +26,7 @@ struct FastParams {
     int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
     int32_t idx_off;       // offset of the class in the dense index blob (see decoder.hip: build_fast_index)
     int32_t G, E, N;
+    int32_t g0;            // first frame group of the launch (the G groups g0 .. g0+G-1 are processed)
     int32_t nz;            // sign threshold (see PassParams)
     int32_t shift_msg;     // log2 of the message alphabet feeding the tables (label = a | b << shift)
     int32_t check, write_hard;
@@ -52,20 +53,23 @@ struct FastParams {
 // every check of degree >= 2 (both are replaced by real magnitudes after two inputs).
 // DEG is the exact check degree (straight-line code, all row loads of UNR checks issued up front);
 // `edges` is the dense [n_nodes][DEG] table of edge ids of this degree class, read with scalar loads.
-template <int DEG, int UNR, int PACK>
-__global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
-    FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+// `block` = index of the 4-wave block within this degree class; PT = FastParams or RoleParams.
+template <int DEG, int UNR, int PACK, typename PT>
+__device__ __forceinline__ void cn_minsum_body(
+    const PT &P, int block, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
-    const int g = wave / P.waves_per_group;
-    if (g >= P.G) return;
-    const int chunk = wave - g * P.waves_per_group;
+    const int wave = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
+    const int gl = wave / P.waves_per_group;
+    if (gl >= P.G) return;
+    const int chunk = wave - gl * P.waves_per_group;
+    const int g = gl + P.g0;
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
-    uint8_t *base = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
+    const rsrc_t base = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's edge rows
+    const uint32_t lane4 = (uint32_t)lane * 4u;
     const int32_t *edges = fast_idx + P.idx_off;
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
@@ -78,19 +82,29 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     const uint32_t odd = (DEG & 1) ? SB : 0u;
     uint32_t failw = 0;
 
-    for (int i = first; i < last; i += UNR) {
-        uint32_t x[UNR][DEG];
-        int e[UNR][DEG];
+    // Software pipeline.  UNR checks are evaluated per step and the rows of the NEXT step are requested
+    // before the current one is evaluated, so a wave keeps UNR*DEG loads in flight while it computes (the
+    // pass needs ~150 rows in flight per CU to cover the HBM latency).  Structure (first step peeled)
+    //     fetch(0) fetch(1) eval(0) { x <- next; fetch(i+2); eval(i+1) }
+    // gives both edges into the loop the same queue of outstanding accesses [loads, stores], which lets the
+    // compiler wait with the exact vmcnt (loads done, the stores behind them still in flight).  A fetch
+    // past the end of the chunk uses an out-of-range lane offset: the buffer unit returns 0 without
+    // touching memory.
+    auto fetch = [&](int i, uint32_t (&xx)[UNR][DEG], int (&ee)[UNR][DEG]) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int ii = (i + u < last) ? i + u : last - 1;
 #pragma unroll
-            for (int k = 0; k < DEG; k++) e[u][k] = edges[(size_t)ii * DEG + k];
+            for (int k = 0; k < DEG; k++) ee[u][k] = edges[(size_t)ii * DEG + k];
         }
 #pragma unroll
-        for (int u = 0; u < UNR; u++)
+        for (int u = 0; u < UNR; u++) {
+            const uint32_t off = lane4 | ((i + u < last) ? 0u : 0x80000000u);
 #pragma unroll
-            for (int k = 0; k < DEG; k++) x[u][k] = *reinterpret_cast<const uint32_t *>(base + (size_t)e[u][k] * kRowBytes);
+            for (int k = 0; k < DEG; k++) xx[u][k] = ld_row(base, (uint32_t)ee[u][k] * kRowBytes, off);
+        }
+    };
+    auto eval = [&](int i, const uint32_t (&x)[UNR][DEG], const int (&e)[UNR][DEG]) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
@@ -125,9 +139,23 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
                 const uint32_t nf = po ^ SB;
                 const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
                 const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
-                *reinterpret_cast<uint32_t *>(base + (size_t)e[u][k] * kRowBytes) = bfi(smask, r, x[u][k]);
+                st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r, x[u][k]));
             }
         }
+    };
+    uint32_t x[UNR][DEG], xn[UNR][DEG];
+    int e[UNR][DEG], en[UNR][DEG];
+    fetch(first, x, e);
+    fetch(first + UNR, xn, en);
+    eval(first, x, e);
+    pipeline_entry_fence();
+    for (int i = first + UNR; i < last; i += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+            for (int k = 0; k < DEG; k++) { x[u][k] = xn[u][k]; e[u][k] = en[u][k]; }
+        fetch(i + UNR, xn, en);
+        eval(i, x, e);
     }
     if (P.check) {
         uint32_t fail[PACK];
@@ -135,6 +163,14 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
         for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
         flag_frames<PACK>(vfail_w, g, lane, fail, amask);
     }
+}
+
+template <int DEG, int UNR, int PACK>
+__global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
+    FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+    const int32_t *__restrict__ fast_idx)
+{
+    cn_minsum_body<DEG, UNR, PACK>(P, (int)blockIdx.x, msgs, state_w, vfail_w, fast_idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -192,26 +228,24 @@ struct Bal {
     static constexpr BalShape<N> S = make_bal_shape<N>();
 };
 
-// One look-up for the four packed frames: label = a | b << sh, table slot `t` in LDS.
-// A 256-entry byte table would span 64 dwords = every LDS bank twice, and two lanes of a 32-lane
-// group reading different dwords of one bank cost an extra cycle (measured: 51 % of the LDS cycles of
-// the degree-8 kernel were such 2-way conflicts).  Tables whose outputs fit 4 bits are therefore staged
-// as NIBBLES: entry i in byte i>>1, low nibble for even i.  128 bytes = 32 dwords = one dword per bank:
-// every access is conflict-free.  The nibble is selected for all four frames at once (SWAR).
-template <bool NIB>
-__device__ __forceinline__ uint32_t lut4(const uint8_t *lds_tab, int t, uint32_t a, uint32_t b, int sh) {
-    const uint32_t L = a | (b << sh);
-    const uint8_t *tb = lds_tab + t * kFastTableStride;
-    if constexpr (NIB) {
-        const uint32_t r0 = tb[(L >> 1) & 0x7Fu], r1 = tb[(L >> 9) & 0x7Fu], r2 = tb[(L >> 17) & 0x7Fu], r3 = tb[L >> 25];
-        const uint32_t R = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-        const uint32_t od = L & 0x01010101u;                    // odd entry -> high nibble
-        const uint32_t M = (od << 4) - od;                      // 0x0F where odd
-        return bfi(M, R >> 4, R) & 0x0F0F0F0Fu;
-    } else {
-        const uint32_t r0 = tb[L & 0xFFu], r1 = tb[(L >> 8) & 0xFFu], r2 = tb[(L >> 16) & 0xFFu], r3 = tb[L >> 24];
-        return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-    }
+// One look-up of ONE frame: label = a | b << sh, table slot `t` in LDS (one v_lshl_or_b32 + one
+// ds_read_u8 with the slot offset as immediate).  The tree of a node is evaluated frame by frame on
+// unpacked labels: keeping four frames packed per register (SWAR) would cost four extractions and three
+// merges around every group of four look-ups -- 2.6 VALU instructions per frame-look-up instead of 1 --
+// and the pass is VALU-bound (gfx950 issues one wave64 VALU instruction per CU per clock).
+// (Packing table entries as nibbles makes the reads bank-conflict free but costs 7 more VALU
+// instructions per four look-ups; measured slower, removed.)
+// The label is formed by an explicit v_lshl_or_b32: written as `a | (b << sh)` the compiler hoists the
+// shared shift `b << sh` of a value that feeds several variants and ends up with MORE instructions
+// (one shift per value plus one OR per label instead of one fused op per label).
+// (x << s) | y in one instruction, s wave-uniform
+__device__ __forceinline__ uint32_t lshl_or(uint32_t x, int s, uint32_t y) {
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t lut1(const uint8_t *lds_tab, int t, uint32_t a, uint32_t b, int sh) {
+    return lds_tab[t * kFastTableStride + lshl_or(b, sh, a)];
 }
 
 // value of child `c` of the balanced tree in variant kc (the first kc leaves of the subtree read
@@ -225,133 +259,231 @@ __device__ __forceinline__ uint32_t bal_child(const uint32_t *in, const uint32_t
     else { constexpr int idx = S.off[C - N] + KC; return v[idx]; }
 }
 
-template <int N, int J, int K, bool NIB>
+template <int N, int J, int K>
 __device__ __forceinline__ void bal_node_variant(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh) {
     constexpr BalShape<N> S = make_bal_shape<N>();
     constexpr int L = S.left[J], R = S.right[J], sl = S.size[L];
     constexpr int kl = K < sl ? K : sl, kr = K > sl ? K - sl : 0;
     constexpr int dst = S.off[J] + K;
-    v[dst] = lut4<NIB>(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
+    v[dst] = lut1(tab, J, bal_child<N, L, kl>(in, v), bal_child<N, R, kr>(in, v), sh);
 }
 
-template <int N, int J, bool NIB, int... Ks>
+template <int N, int J, int... Ks>
 __device__ __forceinline__ void bal_node_all(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Ks...>) {
-    (bal_node_variant<N, J, Ks, NIB>(in, v, tab, sh), ...);
+    (bal_node_variant<N, J, Ks>(in, v, tab, sh), ...);
 }
 // VAR: all variants of every node; DEC (ALL = false): only the unshifted variant K = size
-template <int N, bool ALL, bool NIB, int... Js>
+template <int N, bool ALL, int... Js>
 __device__ __forceinline__ void bal_all_nodes(const uint32_t *in, uint32_t *v, const uint8_t *tab, int sh, std::integer_sequence<int, Js...>) {
-    if constexpr (ALL) (bal_node_all<N, Js, NIB>(in, v, tab, sh, std::make_integer_sequence<int, make_bal_shape<N>().size[N + Js] + 1>{}), ...);
-    else (bal_node_variant<N, Js, make_bal_shape<N>().size[N + Js], NIB>(in, v, tab, sh), ...);
+    if constexpr (ALL) (bal_node_all<N, Js>(in, v, tab, sh, std::make_integer_sequence<int, make_bal_shape<N>().size[N + Js] + 1>{}), ...);
+    else (bal_node_variant<N, Js, make_bal_shape<N>().size[N + Js]>(in, v, tab, sh), ...);
 }
 
 // Variable-node (KIND = TT_VAR) / decision (TT_DEC) pass for degree-DV nodes with balanced trees.
 // Tables: slots 0..NI-1 = internal nodes in creation order, slot NI = root.
 // DV == 1 (VAR only): ROOT(CHA), the build's degree-1 extension.
-template <int DV, int KIND, bool CHECK, int PACK, bool NIB>
-__global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
-    FastParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
+// `block` = index of the 4-wave block within this degree class; lds_tab: >= (NI + 1) * 256 bytes,
+// staged here by the whole block (the call must be block-uniform).
+template <int DV, int KIND, bool CHECK, int PACK, typename PT>
+__device__ __forceinline__ void vn_balanced_body(
+    const PT &P, int block, uint8_t *lds_tab, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
     const int32_t *__restrict__ fast_idx)
 {
     constexpr int N = (KIND == TT_DEC) ? DV : DV - 1;          // message leaves
     constexpr int NI = N > 1 ? N - 1 : 0;
     constexpr int NB = N > 1 ? N : 2;                          // shape used for array sizes when N <= 1
-    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[(NI + 1) * kFastTableStride];
     // stage the class tables (canonical order, fixed 256-byte slots)
     // (table offsets and lengths are multiples of 4: lut_program.hpp pads every table)
-    for (int t = 0; t <= NI; t++) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[t]);
+    {
+        // all table loads first, then all LDS writes: one memory latency per block instead of one per table
+        uint32_t tmp[NI + 1];
         const int i = threadIdx.x;
-        if constexpr (NIB) {
-            // 256 byte entries -> 128 bytes of nibbles: thread i packs entries 8i..8i+7 into one dword
-            if (i < P.tab_len[t] / 8) {
-                const uint32_t lo = src[2 * i], hi = src[2 * i + 1];
-                const uint32_t pl = (lo & 0x0Fu) | ((lo >> 4) & 0xF0u) | ((lo >> 8) & 0xF00u) | ((lo >> 12) & 0xF000u);
-                const uint32_t ph = (hi & 0x0Fu) | ((hi >> 4) & 0xF0u) | ((hi >> 8) & 0xF00u) | ((hi >> 12) & 0xF000u);
-                reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = pl | (ph << 16);
-            }
-        } else {
-            if (i < P.tab_len[t] / 4) reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = src[i];
-        }
+#pragma unroll
+        for (int t = 0; t <= NI; t++) tmp[t] = (i < P.tab_len[t] / 4) ? reinterpret_cast<const uint32_t *>(tables + P.tab_off[t])[i] : 0u;
+#pragma unroll
+        for (int t = 0; t <= NI; t++) if (i < P.tab_len[t] / 4) reinterpret_cast<uint32_t *>(lds_tab + t * kFastTableStride)[i] = tmp[t];
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
-    const int g = wave / P.waves_per_group;
-    if (g >= P.G) return;
-    const int chunk = wave - g * P.waves_per_group;
+    const int wave = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
+    const int gl = wave / P.waves_per_group;
+    if (gl >= P.G) return;
+    const int chunk = wave - gl * P.waves_per_group;
+    const int g = gl + P.g0;
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
     const int32_t *vtab = fast_idx + P.idx_off;                 // dense [n_nodes][2] = {node id, first edge}
-    uint8_t *mbase = msgs + (size_t)g * (size_t)P.E * kRowBytes + lane * 4;
-    const uint8_t *cbase = cha + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
-    uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kRowBytes + lane * 4;
+    const rsrc_t mbase = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's rows
+    const rsrc_t cbase = make_rsrc(cha + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes);
+    uint8_t *hbase = hard + (size_t)g * (size_t)P.N * kRowBytes;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
     const int sh = P.shift_msg, shr = P.tab_shift[NI];
-    uint32_t fail[PACK];
-#pragma unroll
-    for (int h = 0; h < PACK; h++) fail[h] = 0;
+    const int sbit = (KIND == TT_VAR && CHECK) ? __builtin_ctz((unsigned)P.nz | 0x100u) : 0;
+    uint32_t failw = 0;                                          // failed-unanimity flags, one per frame position of the dword
 
-    for (int i = first; i < last; i++) {
-        const int v = vtab[2 * (size_t)i], e0 = vtab[2 * (size_t)i + 1];
-        uint32_t raw[DV + 1];
+    // software pipeline, same structure as cn_minsum_body: the rows of node i+1 are requested before node
+    // i is evaluated, so a wave keeps DV+1 loads in flight during its LDS look-up phase
+    auto fetch = [&](int i, int &vv, int &ee, uint32_t (&r)[DV + 1]) {
+        const int ic = i < last ? i : last - 1;
+        vv = vtab[2 * (size_t)ic]; ee = vtab[2 * (size_t)ic + 1];
+        const uint32_t off = lane4 | (i < last ? 0u : 0x80000000u);      // past the end: out of range, returns 0, no access
 #pragma unroll
-        for (int k = 0; k < DV; k++) raw[k] = *reinterpret_cast<const uint32_t *>(mbase + (size_t)(e0 + k) * kRowBytes);
-        raw[DV] = *reinterpret_cast<const uint32_t *>(cbase + (size_t)v * kRowBytes);
-        uint32_t out[DV], bits[PACK];
+        for (int k = 0; k < DV; k++) r[k] = ld_row(mbase, (uint32_t)(ee + k) * kRowBytes, off);
+        r[DV] = ld_row(cbase, (uint32_t)vv * kRowBytes, off);
+    };
+    auto eval = [&](const uint32_t (&raw)[DV + 1], int v, int e0) {
+        constexpr int F = 4 * PACK, BITS = 8 / PACK;             // frames per dword, bits per label
+        constexpr int U = DV <= 8 ? 2 : 1;                       // frames evaluated per trip (independent: ILP for the LDS latency)
+        constexpr BalShape<NB> SH = make_bal_shape<NB>();
+        constexpr int top_off = SH.off[SH.top - NB];
+        uint32_t out[DV], hardw = 0;
 #pragma unroll
-        for (int h = 0; h < PACK; h++) {
-            uint32_t in[DV + 1];
+        for (int o = 0; o < DV; o++) out[o] = 0;
+        // a real loop over the frames of the dword (not unrolled: one frame's tree keeps ~DV + sum(size+1)
+        // values live, unrolling all frames lets the scheduler interleave them and blows the register budget)
+#pragma unroll 1
+        for (int sp = 0; sp < F * BITS; sp += U * BITS) {
 #pragma unroll
-            for (int k = 0; k <= DV; k++) in[k] = unpack_half<PACK>(raw[k], h);
-            const uint32_t ch = in[DV];
-            constexpr BalShape<NB> SH = make_bal_shape<NB>();
-            constexpr int top_off = SH.off[SH.top - NB];
-            uint32_t val[(N > 1 ? SH.total : 1)];
-            if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR, NIB>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
-            if constexpr (KIND == TT_DEC) {
-                uint32_t top;
-                if constexpr (N > 1) top = val[top_off + N];
-                else top = in[0];
-                bits[h] = swar_lt(lut4<NIB>(lds_tab, NI, top, ch, shr), 1u);     // src/LDPC_Code_LUT.cpp:342
-            } else {
-                uint32_t neg_ref = 0;
+            for (int u = 0; u < U; u++) {                        // frame at bits [s, s + BITS) of every row dword
+                const int s = sp + u * BITS;
+                uint32_t in[DV + 1];
 #pragma unroll
-                for (int o = 0; o < DV; o++) {
-                    uint32_t r;
-                    if constexpr (N == 0) {
-                        // degree 1: the only leaf is the channel label (a one-input table: label = ch)
-                        r = lut4<NIB>(lds_tab, 0, ch, 0u, 0);
-                    } else {
-                        uint32_t top;
-                        if constexpr (N > 1) top = val[top_off + o];
-                        else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
-                        r = lut4<NIB>(lds_tab, NI, top, ch, shr);
+                for (int k = 0; k <= DV; k++) in[k] = __builtin_amdgcn_ubfe(raw[k], (uint32_t)s, (uint32_t)BITS);
+                const uint32_t ch = in[DV];
+                uint32_t val[(N > 1 ? SH.total : 1)];
+                if constexpr (N > 1) bal_all_nodes<N, KIND == TT_VAR>(in, val, lds_tab, sh, std::make_integer_sequence<int, NI>{});
+                if constexpr (KIND == TT_DEC) {
+                    uint32_t top;
+                    if constexpr (N > 1) top = val[top_off + N];
+                    else top = in[0];
+                    hardw = lshl_or(lut1(lds_tab, NI, top, ch, shr) < 1u ? 1u : 0u, s, hardw);     // src/LDPC_Code_LUT.cpp:342
+                } else {
+                    uint32_t r0 = 0, diff = 0;
+#pragma unroll
+                    for (int o = 0; o < DV; o++) {
+                        uint32_t r;
+                        if constexpr (N == 0) {
+                            // degree 1: the only leaf is the channel label (a one-input table: label = ch)
+                            r = lut1(lds_tab, 0, ch, 0u, 0);
+                        } else {
+                            uint32_t top;
+                            if constexpr (N > 1) top = val[top_off + o];
+                            else top = in[o == 0 ? 1 : 0];                     // N == 1: the other message
+                            r = lut1(lds_tab, NI, top, ch, shr);
+                        }
+                        out[o] = lshl_or(r, s, out[o]);
+                        if (CHECK) { if (o == 0) r0 = r; else diff |= r ^ r0; }
                     }
-                    if (PACK == 2 && h == 1) out[o] |= r << 4; else out[o] = r;
                     if (CHECK) {
-                        const uint32_t ng = swar_lt(r, (uint32_t)P.nz);
-                        if (o == 0) neg_ref = ng; else fail[h] |= ng ^ neg_ref;
+                        // sign of a label = bit sbit (nz = 1 << sbit): negative (bit 1 decided) <=> bit clear;
+                        // the node fails the unanimity test when any two outgoing signs differ
+                        hardw = lshl_or(((r0 >> sbit) & 1u) ^ 1u, s, hardw);
+                        failw = lshl_or((diff >> sbit) & 1u, s, failw);
                     }
                 }
-                bits[h] = neg_ref;
             }
         }
         if constexpr (KIND == TT_DEC) {
-            store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes), pack_halves<PACK>(bits), smask);
+            store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         } else {
 #pragma unroll
-            for (int o = 0; o < DV; o++) *reinterpret_cast<uint32_t *>(mbase + (size_t)(e0 + o) * kRowBytes) = bfi(smask, out[o], raw[o]);
+            for (int o = 0; o < DV; o++) st_row(mbase, (uint32_t)(e0 + o) * kRowBytes, lane4, bfi(smask, out[o], raw[o]));
             if (CHECK && P.write_hard)
-                store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes), pack_halves<PACK>(bits), smask);
+                store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         }
+    };
+    int v, e0, vn, en;
+    uint32_t raw[DV + 1], nxt[DV + 1];
+    fetch(first, v, e0, raw);
+    fetch(first + 1, vn, en, nxt);
+    eval(raw, v, e0);
+    pipeline_entry_fence();
+    for (int i = first + 1; i < last; i++) {
+#pragma unroll
+        for (int k = 0; k <= DV; k++) raw[k] = nxt[k];
+        v = vn; e0 = en;
+        fetch(i + 1, vn, en, nxt);
+        eval(raw, v, e0);
     }
-    if (KIND == TT_VAR && CHECK) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    if (KIND == TT_VAR && CHECK) {
+        uint32_t fail[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
+        flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    }
+}
+
+template <int DV, int KIND, bool CHECK, int PACK>
+__global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
+    FastParams P, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
+    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
+    const int32_t *__restrict__ fast_idx)
+{
+    constexpr int NT = (KIND == TT_DEC ? DV : DV - 1) > 1 ? (KIND == TT_DEC ? DV : DV - 1) : 1;   // LUT nodes incl. root
+    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[NT * kFastTableStride];
+    vn_balanced_body<DV, KIND, CHECK, PACK>(P, (int)blockIdx.x, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+}
+
+// ------------------------------------------------------------------------------------------
+// Skewed two-half pipeline: ONE launch that runs a check pass on one half of the frame groups and a
+// variable pass on the other half.  The variable pass is bound by LDS look-ups (34 per frame for a
+// degree-8 node), the check pass by HBM streaming and a little VALU work; taken alone each leaves the
+// other resource idle.  The two halves of a batch are independent decodes, so the host runs them half
+// an iteration out of phase (decoder.hip: decode_tiles_skewed) and every launch mixes both kinds of
+// work on every CU: blocks are handed to roles (degree class x pass kind x half) through an
+// interleaved item table, each block stays homogeneous (one role) so its tables sit at LDS offset 0.
+constexpr int kFusedMaxRoles = 10;
+constexpr int kFusedMaxVnDeg = 8;      // degrees instantiated in the fused kernel (register budget:
+constexpr int kFusedMaxCnDeg = 8;      //  the kernel's VGPR count is the maximum over all cases)
+constexpr int kFusedMaxTables = 8;
+
+struct RoleParams {
+    int32_t kind;          // 0: min-sum check class, 1: variable class
+    int32_t deg;
+    int32_t g0, G;         // frame groups g0 .. g0+G-1
+    int32_t n_nodes, nodes_per_wave, waves_per_group, idx_off;
+    int32_t E, N, nz, shift_msg, check, write_hard;
+    int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
+};
+struct FusedParams {
+    int32_t n_roles;
+    int32_t prio;          // 1: raise the issue priority of the look-up-heavy waves (s_setprio)
+    RoleParams role[kFusedMaxRoles];
+};
+
+template <int PACK, int... Ds>
+__device__ __forceinline__ void fused_cn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *msgs, const uint32_t *state_w,
+                                                uint32_t *vfail_w, const int32_t *fast_idx) {
+    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK>(P, block, msgs, state_w, vfail_w, fast_idx), 0) : 0), ...);
+}
+template <int PACK, bool CHECK, int... Ds>
+__device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *lds_tab, uint8_t *msgs,
+                                                const uint8_t *cha, uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables,
+                                                const int32_t *fast_idx) {
+    ((P.deg == Ds + 1 ? (vn_balanced_body<Ds + 1, TT_VAR, CHECK, PACK>(P, block, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), 0) : 0), ...);
+}
+
+// items[b] = {role, block index within the role}
+template <int PACK, bool CHECK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void pass_fused_kernel(
+    FusedParams FP, const int2 *__restrict__ items, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
+    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[kFusedMaxTables * kFastTableStride];
+    const int2 it = items[blockIdx.x];
+    const int r = __builtin_amdgcn_readfirstlane(it.x), rb = __builtin_amdgcn_readfirstlane(it.y);
+    const RoleParams &P = FP.role[r];
+    if (FP.prio && P.kind) {                       // LUT-heavy waves first: they are the long ones
+        if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+    }
+    if (P.kind == 0) fused_cn_switch<PACK>(P, rb, std::make_integer_sequence<int, kFusedMaxCnDeg - 1>{}, msgs, state_w, vfail_w, fast_idx);
+    else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, kFusedMaxVnDeg>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -430,48 +562,39 @@ inline FastClassPlan plan_fast_vn(const Tree &t, int kind, int d, const std::map
     }
     fp.P.shift_msg = shift_msg < 0 ? 0 : shift_msg;
     fp.P.n_tables = (int)canon.size();
-    // optional nibble staging of 256-entry tables (conflict-free LDS reads, more VALU; measured SLOWER on
-    // MI355X for the DVB-S2 classes, so off unless LUTLDPC_NIB_TABLES=1): needs 4-bit outputs
-    bool want_nib = false, can_nib = true;
-    for (size_t j = 0; j < canon.size(); j++) {
-        if (fp.P.tab_len[j] > 128) want_nib = true;
-        if (canon[j]->K > 16 || (fp.P.tab_len[j] & 7)) can_nib = false;
-    }
-    const char *env = getenv("LUTLDPC_NIB_TABLES");          // minimum degree that gets nibble tables (0 = never)
-    const int nib_min_deg = env ? atoi(env) : 0;
-    fp.P.nib = (nib_min_deg > 0 && d >= nib_min_deg && want_nib && can_nib) ? 1 : 0;
+    fp.P.nib = 0;      // nibble-packed LDS tables (lut4<true>): conflict-free but measured slower on MI355X, not instantiated
     fp.P.deg = d; fp.P.node_off = node_off; fp.P.n_nodes = n_nodes;
     fp.ok = true;
     return fp;
 }
 
+// ------------------------------------------------------------------------------------------
+// Host-side launchers.  They are ordinary (non-inline) function templates, explicitly instantiated in
+// their own translation units (fast_vn_var.hip, fast_vn_dec.hip, fast_cn.hip, fused.hip) so that the
+// ~250 kernel instantiations compile in parallel; decoder.hip sees `extern template` declarations.
+constexpr int kFastMaxDeg = 20;      // variable / decision nodes
+constexpr int kFastMaxCnDeg = 32;    // check nodes
+
 template <int KIND, bool CHECK, int PACK, int DV>
-inline void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
-                               uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
+void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
+                        uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     const int waves = P.waves_per_group * P.G;
-    if (P.nib)
-        hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
-                           tables, fast_idx);
-    else
-        hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
-                           tables, fast_idx);
+    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
+                       tables, fast_idx);
 }
 
 template <int KIND, bool CHECK, int PACK, int... DVs>
-inline bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
-                             uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
+bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
+                      uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     bool done = false;
     ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), done = true) : false), ...);
     return done;
 }
 
-constexpr int kFastMaxDeg = 20;      // variable / decision nodes
-constexpr int kFastMaxCnDeg = 32;    // check nodes
-
 // launch one class; returns false when the degree has no instantiation
 template <int KIND, int PACK>
-inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
-                           uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N) {
+bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
+                    uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N) {
     P.G = G; P.E = E; P.N = N; P.nz = nz; P.check = check; P.write_hard = write_hard;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
@@ -481,19 +604,15 @@ inline bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check
 }
 
 template <int PACK, int DEG>
-inline void launch_cn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
-    // checks in flight per wave: more = more loads outstanding per wave, fewer = fewer VGPRs = more waves
+void launch_cn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+    // checks evaluated per pipeline step: more = more loads outstanding per wave, fewer = fewer VGPRs = more waves
     constexpr int UNR = DEG <= 4 ? 4 : DEG <= 10 ? 2 : 1;
-    static const int unr_env = getenv("LUTLDPC_CN_UNR") ? atoi(getenv("LUTLDPC_CN_UNR")) : 0;
     const int waves = P.waves_per_group * P.G;
-    if (unr_env == 1 || UNR == 1)
-        hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, 1, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
-    else
-        hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
+    hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
 }
 template <int PACK, int... Ds>
-inline bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w,
-                             uint32_t *vfail_w, const int32_t *fast_idx) {
+bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w,
+                      uint32_t *vfail_w, const int32_t *fast_idx) {
     bool done = false;
     ((deg == Ds + 1 ? (launch_cn_fast_one<PACK, Ds + 1>(s, P, msgs, state_w, vfail_w, fast_idx), done = true) : false), ...);
     return done;
@@ -501,8 +620,8 @@ inline bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStre
 
 // min-sum: one launch per degree class
 template <int PACK>
-inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
-                           const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
+                    const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
     if (!is_pow2(nz) || nz > 64 || deg < 2 || deg > kFastMaxCnDeg) return false;
     FastParams P{};
     P.n_nodes = n_nodes; P.idx_off = idx_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg;
@@ -510,5 +629,27 @@ inline bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int
     P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
     return dispatch_cn_fast<PACK>(deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, msgs, state_w, vfail_w, fast_idx);
 }
+
+// skewed pipeline: one launch of pass_fused_kernel over n_blocks items
+template <int PACK>
+void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, int n_blocks, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
+                  const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
+    if (vn_check)
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, true>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
+                           state_w, vfail_w, tables, fast_idx);
+    else
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, false>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
+                           state_w, vfail_w, tables, fast_idx);
+}
+
+#define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
+    X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
+    X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
+    X template bool launch_vn_fast<TT_DEC, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
+    X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
+    X template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
+    X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
+    X template void launch_fused<1>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
+    X template void launch_fused<2>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *);
 
 }  // namespace lutldpc

@@ -344,10 +344,10 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__res
 //   mode 3 (end, value) : ACTIVE -> iters = vfail ? -value : +value
 // vfail is cleared in every mode.
 __global__ __launch_bounds__(256) void frame_state_kernel(uint8_t *__restrict__ state, uint8_t *__restrict__ vfail,
-                                                          int32_t *__restrict__ iters, int B, int Bpad, int mode, int value)
+                                                          int32_t *__restrict__ iters, int B, int f0, int f1, int mode, int value)
 {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= Bpad) return;
+    const int f = f0 + blockIdx.x * 256 + threadIdx.x;      // frames f0 .. f1-1 of the padded batch
+    if (f >= f1) return;
     if (mode == 0) { state[f] = f < B ? ST_ACTIVE : ST_PAD; iters[f] = 0; vfail[f] = 0; return; }
     const uint8_t s = state[f], vf = vfail[f];
     vfail[f] = 0;

@@ -68,6 +68,27 @@ def test_kernel_variants(name, B, snr, env, monkeypatch):
     dec.close()
 
 
+@pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2), ("dvbs2_q4_i6", 1030, 1.0)])
+@pytest.mark.parametrize("env", [{}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}])
+def test_skewed_pipeline(name, B, snr, env, monkeypatch):
+    """Batches of two or more frame groups run as two halves half an iteration out of phase
+    (pass_fused_kernel): uneven halves, ragged last group, early termination on and off."""
+    if name.startswith("dvbs2") and env:
+        pytest.skip("large code: default configuration only")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    desc = dec.describe()
+    # n500_q4 has checks of degree > 8, which the fused kernel does not instantiate: plain pass sequence
+    assert desc["skewed_pipeline"] == (0 if "LUTLDPC_SKEW" in env or name == "n500_q4" else 1), desc
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=4242)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, True, False)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
 @pytest.mark.parametrize("B", [1, 3, 255, 256, 257, 511, 512, 513])
 def test_batch_sizes(B):
     cd = oracle_codec("n500_q4_i8")
