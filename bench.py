@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--snr", type=float, default=None, help="Eb/N0 in dB of the synthetic frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not bracket the kernels with HIP events")
+    ap.add_argument("--frame-loop-steps", type=int, default=2, help="extra untimed-for-`value` steps of the full sampler+decode+count loop (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -228,6 +229,22 @@ def main():
         "counters": {"frames": int(counters[0]), "data_bits": int(counters[1]), "frame_errors": int(counters[2]),
                      "data_bit_errors": int(counters[3]), "uncoded_bit_errors": int(counters[4])},
     }
+    if args.frame_loop_steps > 0:
+        # The whole frame loop of LDPC_BER_Sim::sim_snr_point (src/LDPC_BER_Sim.cpp:260-291) on the device:
+        # channel sampler -> decode -> error counting, labels never leave HBM.  Reported beside `value`
+        # (which stays the decode throughput on resident labels), not instead of it.
+        cd.sim_batch(snr, 99, 0, 0, B)
+        dec.set_profiling(True); dec.reset_profile()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.frame_loop_steps):
+            st = cd.sim_batch(snr, 99, 0, (k + 1) * B, B)
+        t_loop = time.perf_counter() - t1
+        pf = dec.profile(); dec.set_profiling(False)
+        result["frame_loop"] = {"codewords_per_s_per_gpu": B * args.frame_loop_steps / t_loop, "steps": args.frame_loop_steps,
+                                "frontend_ms_per_step": pf["frontend"]["ms"] / args.frame_loop_steps,
+                                "frame_errors_last_step": int((st[:, 1] != 0).sum()),
+                                "note": "device sampler (Philox4x32-10 cell sampler) + decode + BER/FER counting, zero codeword"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ob, oi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
         n = len(oi)

@@ -299,7 +299,13 @@ int upload_static(lutldpc_decoder *d) {
     HIP_TRY(d->d_vn_ptr.upload(d->vn_ptr));
     HIP_TRY(d->d_cn_ptr.upload(d->cn_ptr));
     HIP_TRY(d->d_cn_idx.upload(d->cn_msg_idx));
-    HIP_TRY(d->d_cn_vn.upload(d->cn_vn));
+    {   // syndrome kernel: node of every check-edge, bit 31 = last edge of its check, 8 entries of padding
+        std::vector<int32_t> f((size_t)d->E + 8, 0);
+        for (int c = 0; c < d->nchk; c++)
+            for (int k = d->cn_ptr[(size_t)c]; k < d->cn_ptr[(size_t)c + 1]; k++)
+                f[(size_t)k] = (int32_t)((uint32_t)d->cn_vn[(size_t)k] | (k + 1 == d->cn_ptr[(size_t)c + 1] ? 0x80000000u : 0u));
+        HIP_TRY(d->d_cn_vn.upload(f));
+    }
     HIP_TRY(d->d_vn_list.upload(d->vn_list));
     HIP_TRY(d->d_cn_list.upload(d->cn_list));
     HIP_TRY(d->d_fast_idx.upload(d->fast_idx));
@@ -357,7 +363,27 @@ int launch_syndrome(lutldpc_decoder *d, int G) {
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
     PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                        reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                       d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, d->nvar, cpw));
+                       d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
+// frame-major [B][N] <-> rows; the dword-vectorised kernels need N % 4 == 0 and a 4-byte aligned buffer
+int launch_transpose_in(lutldpc_decoder *d, const uint8_t *src, uint8_t *dst_rows, int B, int G, int limit) {
+    const int N = d->nvar;
+    if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0)
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
+    else
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+int launch_transpose_out(lutldpc_decoder *d, const uint8_t *src_rows, uint8_t *dst, int B, int G) {
+    const int N = d->nvar;
+    if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
+    else
+        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -625,15 +651,14 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
         dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, grid, dim3(256), 0, d->stream, d_cha, d->d_cha_t.p, B, N, d->Nq_Cha));
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, grid, dim3(256), 0, d->stream, d_msg0, d->d_msg0_t.p, B, N, d->Nq_Msg[0]));
+        if ((rc = launch_transpose_in(d, d_cha, d->d_cha_t.p, B, G, d->Nq_Cha))) return rc;
+        if ((rc = launch_transpose_in(d, d_msg0, d->d_msg0_t.p, B, G, d->Nq_Msg[0]))) return rc;
         LAUNCH_CHECK();
     }
     if ((rc = decode_tiles(d, B))) return rc;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p, d_out_bits, B, N));
-        LAUNCH_CHECK();
+        if ((rc = launch_transpose_out(d, d->d_hard.p, d_out_bits, B, G))) return rc;
         HIP_TRY(hipMemcpyAsync(d_out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToDevice, d->stream));
     }
     return LUTLDPC_OK;
@@ -895,12 +920,12 @@ int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *c
         HIP_TRY(d->d_out_bits.alloc(n));
         dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
         if (cha_out) {
-            PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_out_bits.p, B, N));
+            if ((rc = launch_transpose_out(d, d->d_cha_t.p, d->d_out_bits.p, B, G))) return rc;
             LAUNCH_CHECK();
             HIP_TRY(hipMemcpyAsync(cha_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
         }
         if (bits_out) {
-            PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_hard.p, d->d_out_bits.p, B, N));
+            if ((rc = launch_transpose_out(d, d->d_hard.p, d->d_out_bits.p, B, G))) return rc;
             LAUNCH_CHECK();
             HIP_TRY(hipMemcpyAsync(bits_out, d->d_out_bits.p, n, hipMemcpyDeviceToHost, d->stream));
         }
@@ -923,9 +948,8 @@ int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cell
     const size_t n = (size_t)B * N;
     HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n));
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
-    PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_cha_t.p, d->d_in_cha.p, B, N));
-    PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, grid, dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_in_msg.p, B, N));
-    LAUNCH_CHECK();
+    if ((rc = launch_transpose_out(d, d->d_cha_t.p, d->d_in_cha.p, B, G))) return rc;
+    if ((rc = launch_transpose_out(d, d->d_msg0_t.p, d->d_in_msg.p, B, G))) return rc;
     HIP_TRY(hipMemcpyAsync(cha, d->d_in_cha.p, n, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipMemcpyAsync(msg0, d->d_in_msg.p, n, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));

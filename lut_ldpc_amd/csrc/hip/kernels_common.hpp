@@ -149,7 +149,12 @@ __device__ __forceinline__ void flag_frames(uint32_t *__restrict__ vfail_w, int 
 #pragma unroll
     for (int h = 0; h < PACK; h++) {
         const uint32_t f = fail[h] & amask[h] & 0x01010101u;
-        if (f) atomicOr(&vfail_w[frame_word<PACK>(g, lane, h)], f);
+        // a failing frame fails in thousands of waves: look before the atomic, so that only the first few
+        // per word reach the L2 atomic unit (the OR is idempotent, a stale read only costs one more atomic)
+        if (f) {
+            uint32_t *p = &vfail_w[frame_word<PACK>(g, lane, h)];
+            if ((__builtin_nontemporal_load(p) & f) != f) atomicOr(p, f);
+        }
     }
 }
 

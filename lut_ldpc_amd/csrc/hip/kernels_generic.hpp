@@ -286,6 +286,95 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const uint8_t *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Vectorised transposes (N % 4 == 0, 4-byte aligned frame-major buffer): a block moves 128 nodes x one
+// frame group through LDS as DWORDS (4 nodes of one frame each).
+//   global side : 32 lanes x 4 B = 128 contiguous bytes per frame;
+//   LDS         : tile[f][c ^ key(f)], key(f) = (f / frames-per-lane) & 31: the XOR swizzle makes both the
+//                 frame-major side (32 lanes, one frame, all quads c) and the row side (lane L reads its own
+//                 frames 4*PACK*L + k of one quad c) hit 32 different banks;
+//   registers   : 4x4 byte transposes with v_perm_b32 turn "4 nodes of 4 frames" into "4 frames of one node",
+//                 the dword a lane owns in a row (PACK = 2: two of them merged as low / high nibbles).
+__device__ __forceinline__ void transpose4x4(uint32_t (&d)[4]) {
+    const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);
+    const uint32_t c = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u), e = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+    d[0] = __builtin_amdgcn_perm(c, a, 0x05040100u); d[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    d[2] = __builtin_amdgcn_perm(e, b, 0x05040100u); d[3] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+}
+
+template <int PACK>
+__global__ __launch_bounds__(256) void transpose_in_vec_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int B, int N, int limit)
+{
+    constexpr int F = kRowBytes * PACK, FPL = 4 * PACK;     // frames per group / per lane
+    __shared__ uint32_t tile[F * 32];
+    const int g = blockIdx.y, n0 = blockIdx.x * 128, t = threadIdx.x;
+    const int c = t & 31, fq = t >> 5;
+    const uint32_t lim = (uint32_t)(limit - 1);
+    for (int f0 = fq; f0 < F; f0 += 64) {                   // eight loads in flight per thread
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int fr = g * F + f0 + 8 * j, n = n0 + 4 * c;
+            v[j] = (fr < B && n < N) ? *reinterpret_cast<const uint32_t *>(src + (size_t)fr * N + n) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int f = f0 + 8 * j;
+            const uint32_t b0 = min(v[j] & 0xFFu, lim), b1 = min((v[j] >> 8) & 0xFFu, lim), b2 = min((v[j] >> 16) & 0xFFu, lim), b3 = min(v[j] >> 24, lim);
+            tile[f * 32 + (c ^ ((f / FPL) & 31))] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+    }
+    __syncthreads();
+    const int lane = t & 63;
+    for (int q = t >> 6; q < 32; q += 4) {                  // node quad q: nodes n0 + 4q .. +3
+        if (n0 + 4 * q >= N) break;
+        uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < PACK; h++) {
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = tile[(FPL * lane + 4 * h + k) * 32 + (q ^ (lane & 31))];
+            transpose4x4(d);
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[k] |= d[k] << (4 * h);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            *reinterpret_cast<uint32_t *>(dst + ((size_t)g * N + n0 + 4 * q + k) * kRowBytes + lane * 4) = out[k];
+    }
+}
+
+template <int PACK>
+__global__ __launch_bounds__(256) void transpose_out_vec_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int B, int N)
+{
+    constexpr int F = kRowBytes * PACK, FPL = 4 * PACK;
+    __shared__ uint32_t tile[F * 32];
+    const int g = blockIdx.y, n0 = blockIdx.x * 128, t = threadIdx.x;
+    const int lane = t & 63;
+    for (int q = t >> 6; q < 32; q += 4) {
+        uint32_t x[4] = {0, 0, 0, 0};
+        if (n0 + 4 * q < N) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[k] = *reinterpret_cast<const uint32_t *>(src + ((size_t)g * N + n0 + 4 * q + k) * kRowBytes + lane * 4);
+        }
+#pragma unroll
+        for (int h = 0; h < PACK; h++) {
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = unpack_half<PACK>(x[k], h);
+            transpose4x4(d);                                 // d[k] = 4 nodes of frame FPL*lane + 4h + k
+#pragma unroll
+            for (int k = 0; k < 4; k++) tile[(FPL * lane + 4 * h + k) * 32 + (q ^ (lane & 31))] = d[k];
+        }
+    }
+    __syncthreads();
+    const int c = t & 31, fq = t >> 5;
+    for (int f = fq; f < F; f += 8) {
+        const int fr = g * F + f, n = n0 + 4 * c;
+        if (fr < B && n < N) *reinterpret_cast<uint32_t *>(dst + (size_t)fr * N + n) = tile[f * 32 + (c ^ ((f / FPL) & 31))];
+    }
+}
+
 // msgs[g][e][:] = msg0[g][v(e)][:]  (src/LDPC_Code_LUT.cpp:284-289); one wave per VN (rows are copied whole)
 __global__ __launch_bounds__(256) void init_edges_kernel(const uint8_t *__restrict__ msg0_t, uint8_t *__restrict__ msgs,
                                                          const int32_t *__restrict__ vn_ptr, int N, int E)
@@ -312,24 +401,43 @@ __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__
     reinterpret_cast<uint32_t *>(hard)[i] = pack_halves<PACK>(r);
 }
 
-// parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome
+// parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome.
+// cn_vnf[k] = variable node of check-edge k, bit 31 set on the last edge of its check; padded with 8
+// zero entries.  A wave walks the run of edges of its checks eight at a time: ONE vector load fetches
+// the eight indices (lanes 0..7), v_readlane turns them into wave-uniform row offsets, the eight row
+// loads go out together (a lane offset past the end of the run is out of range: returns 0, neutral
+// for the XOR), and the running parity is closed branch-free where the flag is set.
 template <int PACK>
 __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__restrict__ hard, const uint32_t *__restrict__ state_w,
                                                             uint32_t *__restrict__ vfail_w, const int32_t *__restrict__ cn_ptr,
-                                                            const int32_t *__restrict__ cn_vn, int M, int N, int checks_per_wave)
+                                                            const uint32_t *__restrict__ cn_vnf, int M, int N, int checks_per_wave)
 {
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int c0 = w * checks_per_wave, c1 = c0 + checks_per_wave;
     if (c1 > M) c1 = M;
-    uint32_t acc = 0;
-    for (int c = c0; c < c1; c++) {
-        uint32_t s = 0;
-        for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++)
-            s ^= *reinterpret_cast<const uint32_t *>(hard + ((size_t)g * N + cn_vn[k]) * kRowBytes + lane * 4);
-        acc |= s;
+    if (c0 >= c1) return;
+    const rsrc_t hb = make_rsrc(hard + (size_t)g * (size_t)N * kRowBytes, (uint32_t)N * kRowBytes);
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const int k0 = cn_ptr[c0], k1 = cn_ptr[c1];
+    uint32_t acc = 0, s = 0;
+    for (int k = k0; k < k1; k += 8) {
+        const uint32_t mine = cn_vnf[k + (lane & 7)];
+        uint32_t x[8], last[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+            last[j] = (k + j < k1) ? (uint32_t)((int32_t)e >> 31) : 0u;                      // 0 or ~0, wave-uniform
+            x[j] = ld_row(hb, (e & 0x7FFFFFFFu) * kRowBytes, lane4 | (k + j < k1 ? 0u : 0x80000000u));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s ^= x[j];
+            acc |= s & last[j];
+            s &= ~last[j];
+        }
     }
     uint32_t fail[PACK];
 #pragma unroll
