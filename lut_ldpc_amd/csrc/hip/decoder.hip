@@ -327,7 +327,7 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_hard.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_state.alloc((size_t)Bpad));
-    HIP_TRY(d->d_vfail.alloc((size_t)Bpad));
+    HIP_TRY(d->d_vfail.alloc((size_t)Bpad * kVfailSlots));      // kVfailSlots copies, Bcap bytes apart (flag_frames)
     HIP_TRY(d->d_iters.alloc((size_t)Bpad));
     d->Bcap = Bpad;
     return LUTLDPC_OK;
@@ -352,7 +352,7 @@ int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value, int f
     if (f1 < 0) f1 = Bpad;
     if (f1 <= f0) return LUTLDPC_OK;
     hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)((f1 - f0) / 256)), dim3(256), 0, d->stream,
-                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, f0, f1, mode, value);
+                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, f0, f1, mode, value, d->Bcap);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -363,7 +363,7 @@ int launch_syndrome(lutldpc_decoder *d, int G) {
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
     PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                        reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
-                       d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw));
+                       d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw, d->Bcap / 4));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -409,7 +409,7 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
     if (!plan.valid) return fail(LUTLDPC_ERR_STATE, "pass plan missing for this tree set");
     Timed t(d, kind_id);
     PassParams P = plan.P;
-    P.G = G; P.nz = nz; P.check = check; P.write_hard = write_hard;
+    P.G = G; P.nz = nz; P.check = check; P.write_hard = write_hard; P.vfail_stride_w = d->Bcap / 4;
     std::vector<char> keep((size_t)P.n_seg, 1);
     bool any = false;
     // specialised kernels take the classes they know, one launch per degree class
@@ -419,7 +419,7 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
             bool ok = false;
             PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->npw_vn((*fast)[(size_t)i].P.deg), d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
                                      reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
-                                     d->d_fast_idx.p, d->E, d->nvar));
+                                     d->d_fast_idx.p, d->E, d->nvar, d->Bcap / 4));
             if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
@@ -444,14 +444,14 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
 int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     Timed t(d, LUTLDPC_K_CN_PASS);
     PassParams P = d->cn_minsum_plan.P;
-    P.G = G; P.nz = nz; P.check = check;
+    P.G = G; P.nz = nz; P.check = check; P.vfail_stride_w = d->Bcap / 4;
     std::vector<char> keep((size_t)P.n_seg, 1);
     bool any = false;
     if (d->use_fast)
         for (int i = 0; i < P.n_seg; i++) {
             bool ok = false;
             PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->npw_cn(P.seg[i].deg), d->d_msgs.p,
-                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p));
+                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p, d->Bcap / 4));
             if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
@@ -491,7 +491,7 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         R.kind = 0; R.deg = d->cclass[i].deg; R.g0 = h.g0; R.G = h.G;
         R.n_nodes = (int)d->cclass[i].nodes.size(); R.nodes_per_wave = npw;
         R.waves_per_group = (R.n_nodes + npw - 1) / npw;
-        R.idx_off = d->cn_idx_off[i]; R.E = d->E; R.N = d->nvar; R.nz = nz; R.check = check;
+        R.idx_off = d->cn_idx_off[i]; R.E = d->E; R.N = d->nvar; R.nz = nz; R.check = check; R.vfail_stride_w = d->Bcap / 4;
         FP.role[FP.n_roles++] = R;
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
     }
@@ -504,7 +504,7 @@ void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         R.kind = 1; R.deg = F.deg; R.g0 = h.g0; R.G = h.G;
         R.n_nodes = F.n_nodes; R.nodes_per_wave = npw;
         R.waves_per_group = (R.n_nodes + npw - 1) / npw;
-        R.idx_off = F.idx_off; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard;
+        R.idx_off = F.idx_off; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard; R.vfail_stride_w = d->Bcap / 4;
         for (int t = 0; t < F.n_tables; t++) { R.tab_off[t] = F.tab_off[t]; R.tab_len[t] = F.tab_len[t]; R.tab_shift[t] = F.tab_shift[t]; }
         FP.role[FP.n_roles++] = R;
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);

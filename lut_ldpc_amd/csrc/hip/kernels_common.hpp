@@ -54,6 +54,7 @@ struct PassParams {
     int32_t check;         // 1: accumulate the early-termination test into vfail
     int32_t write_hard;    // VN pass: store the sign of the new messages as hard decisions
     int32_t slots_lds;     // dwords per lane reserved for program slots
+    int32_t vfail_stride_w;   // words between two copies of the early-termination flags (see flag_frames)
     PassSeg seg[kMaxSeg];
 };
 
@@ -144,17 +145,19 @@ __device__ __forceinline__ void store_row_masked(uint32_t *p, uint32_t val, uint
     else if (smask) *p = bfi(smask, val, *p);
 }
 
+// Early-termination flags.  A failing frame fails in thousands of waves of one launch and all waves of a
+// frame group own the same frames, so a single flag word per four frames would serialise ~10^4 atomics
+// per launch on a handful of L2 lines (measured: +60 % on the whole pass).  The flags are therefore
+// kept in kVfailSlots copies (slot = block index mod kVfailSlots, `stride_w` words apart); the atomics
+// are fire-and-forget (no return value) and frame_state_kernel ORs the copies together.
+constexpr int kVfailSlots = 32;
 template <int PACK>
-__device__ __forceinline__ void flag_frames(uint32_t *__restrict__ vfail_w, int g, int lane, const uint32_t (&fail)[PACK], const uint32_t (&amask)[PACK]) {
+__device__ __forceinline__ void flag_frames(uint32_t *__restrict__ vfail_w, int stride_w, int g, int lane, const uint32_t (&fail)[PACK], const uint32_t (&amask)[PACK]) {
+    uint32_t *slot = vfail_w + (size_t)(blockIdx.x & (kVfailSlots - 1)) * (size_t)stride_w;
 #pragma unroll
     for (int h = 0; h < PACK; h++) {
         const uint32_t f = fail[h] & amask[h] & 0x01010101u;
-        // a failing frame fails in thousands of waves: look before the atomic, so that only the first few
-        // per word reach the L2 atomic unit (the OR is idempotent, a stale read only costs one more atomic)
-        if (f) {
-            uint32_t *p = &vfail_w[frame_word<PACK>(g, lane, h)];
-            if ((__builtin_nontemporal_load(p) & f) != f) atomicOr(p, f);
-        }
+        if (f) atomicOr(&slot[frame_word<PACK>(g, lane, h)], f);
     }
 }
 

@@ -35,7 +35,8 @@ struct FastParams {
     int32_t tab_off[kFastMaxTables];    // byte offsets into the table blob, canonical node order
     int32_t tab_len[kFastMaxTables];
     int32_t tab_shift[kFastMaxTables];  // log2 alphabet of each table's first child
-    int32_t nib;                        // 1: tables staged as nibbles (two entries per byte), see lut4
+    int32_t nib;                        // (unused: nibble-packed LDS tables were measured slower and removed)
+    int32_t vfail_stride_w;             // words between two copies of the early-termination flags (see flag_frames)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -161,7 +162,7 @@ __device__ __forceinline__ void cn_minsum_body(
         uint32_t fail[PACK];
 #pragma unroll
         for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
-        flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+        flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
     }
 }
 
@@ -415,7 +416,7 @@ __device__ __forceinline__ void vn_balanced_body(
         uint32_t fail[PACK];
 #pragma unroll
         for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
-        flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+        flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
     }
 }
 
@@ -449,6 +450,7 @@ struct RoleParams {
     int32_t g0, G;         // frame groups g0 .. g0+G-1
     int32_t n_nodes, nodes_per_wave, waves_per_group, idx_off;
     int32_t E, N, nz, shift_msg, check, write_hard;
+    int32_t vfail_stride_w;
     int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
 };
 struct FusedParams {
@@ -594,7 +596,8 @@ bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s
 // launch one class; returns false when the degree has no instantiation
 template <int KIND, int PACK>
 bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
-                    uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N) {
+                    uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N, int vfail_stride_w) {
+    P.vfail_stride_w = vfail_stride_w;
     P.G = G; P.E = E; P.N = N; P.nz = nz; P.check = check; P.write_hard = write_hard;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
@@ -621,10 +624,10 @@ bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s,
 // min-sum: one launch per degree class
 template <int PACK>
 bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
-                    const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+                    const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx, int vfail_stride_w) {
     if (!is_pow2(nz) || nz > 64 || deg < 2 || deg > kFastMaxCnDeg) return false;
     FastParams P{};
-    P.n_nodes = n_nodes; P.idx_off = idx_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg;
+    P.n_nodes = n_nodes; P.idx_off = idx_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg; P.vfail_stride_w = vfail_stride_w;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
     return dispatch_cn_fast<PACK>(deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, msgs, state_w, vfail_w, fast_idx);
@@ -643,12 +646,12 @@ void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, in
 }
 
 #define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
-    X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
-    X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
-    X template bool launch_vn_fast<TT_DEC, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
-    X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int); \
-    X template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
-    X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
+    X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
+    X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
+    X template bool launch_vn_fast<TT_DEC, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
+    X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
+    X template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
+    X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
     X template void launch_fused<1>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
     X template void launch_fused<2>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *);
 

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void tree_pass_kernel(
                 store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + (gN + (size_t)node) * kRowBytes + lane * 4), pack_halves<PACK>(neg_ref), smask);
         }
     }
-    if (KIND != TT_DEC && P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    if (KIND != TT_DEC && P.check) flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void cn_minsum_generic_kernel(
             *row = bfi(smask, pack_halves<PACK>(rr), xr);
         }
     }
-    if (P.check) flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    if (P.check) flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__
 template <int PACK>
 __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__restrict__ hard, const uint32_t *__restrict__ state_w,
                                                             uint32_t *__restrict__ vfail_w, const int32_t *__restrict__ cn_ptr,
-                                                            const uint32_t *__restrict__ cn_vnf, int M, int N, int checks_per_wave)
+                                                            const uint32_t *__restrict__ cn_vnf, int M, int N, int checks_per_wave, int vfail_stride_w)
 {
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     uint32_t amask[PACK];
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__res
     uint32_t fail[PACK];
 #pragma unroll
     for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(acc, h);
-    flag_frames<PACK>(vfail_w, g, lane, fail, amask);
+    flag_frames<PACK>(vfail_w, vfail_stride_w, g, lane, fail, amask);
 }
 
 // per-frame state machine between passes
@@ -452,13 +452,15 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__res
 //   mode 3 (end, value) : ACTIVE -> iters = vfail ? -value : +value
 // vfail is cleared in every mode.
 __global__ __launch_bounds__(256) void frame_state_kernel(uint8_t *__restrict__ state, uint8_t *__restrict__ vfail,
-                                                          int32_t *__restrict__ iters, int B, int f0, int f1, int mode, int value)
+                                                          int32_t *__restrict__ iters, int B, int f0, int f1, int mode, int value, int vfail_stride)
 {
     const int f = f0 + blockIdx.x * 256 + threadIdx.x;      // frames f0 .. f1-1 of the padded batch
     if (f >= f1) return;
-    if (mode == 0) { state[f] = f < B ? ST_ACTIVE : ST_PAD; iters[f] = 0; vfail[f] = 0; return; }
-    const uint8_t s = state[f], vf = vfail[f];
-    vfail[f] = 0;
+    uint8_t vf = 0;                                         // OR of the kVfailSlots copies (flag_frames), then clear them
+    if (mode != 0) for (int s = 0; s < kVfailSlots; s++) vf |= vfail[(size_t)s * vfail_stride + f];
+    for (int s = 0; s < kVfailSlots; s++) vfail[(size_t)s * vfail_stride + f] = 0;
+    if (mode == 0) { state[f] = f < B ? ST_ACTIVE : ST_PAD; iters[f] = 0; return; }
+    const uint8_t s = state[f];
     if (s != ST_ACTIVE) return;
     if (mode == 1) { if (!vf) { state[f] = ST_DONE_PISC; iters[f] = 0; } }
     else if (mode == 2) { if (!vf) { state[f] = ST_DONE_PSC; iters[f] = value; } }
