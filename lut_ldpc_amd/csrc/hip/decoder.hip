@@ -14,6 +14,7 @@
 namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast_*.hip / fused.hip
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -117,13 +118,20 @@ struct lutldpc_decoder {
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
     int vn_edges_per_wave = 32, cn_edges_per_wave = 56;
     int fused_prio = 0;
+    int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
+    struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
+    std::map<std::array<int, 4>, GraphSlot> graphs;       // key {B, psc, pisc, max_iters}
+    void drop_graphs() { for (auto &kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); graphs.clear(); }
     double tail_front = 0.15;   // fused launches: fraction of the item list that the slowest role stays clear of at the end
-    int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, vn_edges_per_wave / std::max(deg, 1)); }
-    int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, cn_edges_per_wave / std::max(deg, 1)); }
+    // (halving the per-wave work for short codes so that a pass has more waves was measured slower: -13 % on N=500)
+    static constexpr int work_shift = 0;
+    int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, (vn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
+    int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, (cn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
     int use_fast = 1;
     int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
     int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (needs G >= 2)
     bool skew_ok = false;       // every class of every set has a case in the fused kernel
+    int fused_bucket_id = 0;    // degree bucket of the fused kernel (kernels_fast.hpp: kFusedVnDeg / kFusedCnDeg)
     std::map<std::vector<int>, std::unique_ptr<DevBuf<int32_t>>> item_tabs;   // role block counts -> interleaved item table
     int tile() const { return kRowBytes * pack; }       // frames per group
     int bpad(int B) const { return (B + tile() - 1) / tile() * tile(); }
@@ -322,6 +330,7 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     int Bpad = d->bpad(B);
     if (Bpad <= d->Bcap) return LUTLDPC_OK;
     size_t G = (size_t)(Bpad / d->tile());
+    d->drop_graphs();                                // the captured launches hold the old buffer addresses
     HIP_TRY(d->d_msgs.alloc(G * (size_t)d->E * kRowBytes));
     HIP_TRY(d->d_cha_t.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kRowBytes));
@@ -474,12 +483,15 @@ struct HalfRange { int g0, G; };
 bool skew_eligible(const lutldpc_decoder *d) {
     if (!d->min_lut || !d->use_fast) return false;
     if ((int)(d->cclass.size() + d->vclass.size()) > kFusedMaxRoles) return false;
-    for (auto &c : d->cclass) if (c.deg < 2 || c.deg > kFusedMaxCnDeg) return false;
+    int max_cn = 0, max_vn = 0;
+    for (auto &c : d->cclass) { if (c.deg < 2) return false; max_cn = std::max(max_cn, c.deg); }
+    for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
+    if (fused_bucket(max_vn, max_cn) < 0) return false;
     for (int nq : d->Nq_Msg) if (!is_pow2(nq / 2) || nq / 2 > 64) return false;
     for (size_t s = 0; s < d->var_fast.size(); s++) {
         if (d->var_plan[s].valid == false) continue;          // decision-only set
         for (auto &f : d->var_fast[s])
-            if (!f.ok || f.P.nib || f.P.deg > kFusedMaxVnDeg || f.P.n_tables > kFusedMaxTables) return false;
+            if (!f.ok || f.P.n_tables > kFusedMaxTables) return false;
     }
     return true;
 }
@@ -552,8 +564,12 @@ int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vect
     if ((rc = item_table(d, blocks, front, &items, &nb))) return rc;
     if (nb == 0) return LUTLDPC_OK;
     Timed t(d, LUTLDPC_K_FUSED_PASS);
-    PACK_DISPATCH(d, lutldpc::launch_fused<PK>(d->stream, FP, items, nb, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p),
-                                              reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p));
+#define FUSED_ARGS d->stream, FP, items, nb, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), \
+                   reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p
+    if (d->fused_bucket_id == 0) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 0>(FUSED_ARGS)));
+    else if (d->fused_bucket_id == 1) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 1>(FUSED_ARGS)));
+    else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
+#undef FUSED_ARGS
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -592,7 +608,7 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
 
 // Core: decode the B frames whose labels are already in tile layout (d_cha_t / d_msg0_t).
 // Leaves the decided bits in d_hard (tile layout) and the iteration codes in d_iters.
-int decode_tiles(lutldpc_decoder *d, int B) {
+int decode_tiles_launch(lutldpc_decoder *d, int B) {
     int rc;
     const int Bpad = d->bpad(B), G = Bpad / d->tile();
     const int N = d->nvar, E = d->E, I = d->max_iters;
@@ -636,6 +652,36 @@ int decode_tiles(lutldpc_decoder *d, int B) {
     if ((rc = launch_syndrome(d, G))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
     if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
+    return LUTLDPC_OK;
+}
+
+// A decode is 100-300 short launches whose arguments depend only on (B, exit conditions): from the
+// second call with the same key on, the sequence is replayed as ONE hipGraph launch (the first call runs
+// plainly and fills the item-table cache, whose uploads may not happen inside a capture).  Short codes
+// are launch-bound, for them this is worth ~20 %.  Off while kernel events are being recorded.
+int decode_tiles(lutldpc_decoder *d, int B) {
+    if (!d->use_graph || d->profiling) return decode_tiles_launch(d, B);
+    const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
+    auto &slot = d->graphs[key];
+    if (slot.exec) {
+        HIP_TRY(hipGraphLaunch(slot.exec, d->stream));
+        return LUTLDPC_OK;
+    }
+    if (slot.seen++ == 0) return decode_tiles_launch(d, B);
+    HIP_TRY(hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = decode_tiles_launch(d, B);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(d->stream, &g);
+    if (rc || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        d->use_graph = 0;                             // capture not possible here: plain launches from now on
+        return rc ? rc : decode_tiles_launch(d, B);
+    }
+    const hipError_t ei = hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { slot.exec = nullptr; d->use_graph = 0; (void)hipGetLastError(); return decode_tiles_launch(d, B); }
+    HIP_TRY(hipGraphLaunch(slot.exec, d->stream));
     return LUTLDPC_OK;
 }
 
@@ -718,7 +764,7 @@ void make_describe(lutldpc_decoder *d) {
         o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size() << ",\"kernel\":\""
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel") : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << "}";
     d->describe = o.str();
 }
 
@@ -798,6 +844,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     d->nodes_per_wave_cn = d->nodes_per_wave;
     if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE_CN")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave_cn = v; }
@@ -805,6 +852,12 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     int rc = compile_all(d.get());
     if (rc) return rc;
     d->skew_ok = skew_eligible(d.get());
+    {
+        int max_cn = 0, max_vn = 0;
+        for (auto &c : d->cclass) max_cn = std::max(max_cn, c.deg);
+        for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
+        d->fused_bucket_id = std::max(0, fused_bucket(max_vn, max_cn));
+    }
     d->device = device;
     if (device >= 0) { rc = upload_static(d.get()); if (rc) return rc; }
     make_describe(d.get());
@@ -822,6 +875,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
+        d->drop_graphs();
         for (auto &kv : d->item_tabs) kv.second->release();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);

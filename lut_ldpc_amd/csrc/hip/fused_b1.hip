@@ -1,0 +1,6 @@
+// fused_b1.hip -- explicit instantiation of the fused pass kernel, degree bucket 1 (see kernels_fast.hpp)
+#include "kernels_fast.hpp"
+namespace lutldpc {
+template void launch_fused<1, 1> LUTLDPC_FUSED_SIG;
+template void launch_fused<2, 1> LUTLDPC_FUSED_SIG;
+}

@@ -1,0 +1,6 @@
+// fused_b2.hip -- explicit instantiation of the fused pass kernel, degree bucket 2 (see kernels_fast.hpp)
+#include "kernels_fast.hpp"
+namespace lutldpc {
+template void launch_fused<1, 2> LUTLDPC_FUSED_SIG;
+template void launch_fused<2, 2> LUTLDPC_FUSED_SIG;
+}

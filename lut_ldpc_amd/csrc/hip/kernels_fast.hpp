@@ -144,19 +144,30 @@ __device__ __forceinline__ void cn_minsum_body(
             }
         }
     };
-    uint32_t x[UNR][DEG], xn[UNR][DEG];
-    int e[UNR][DEG], en[UNR][DEG];
-    fetch(first, x, e);
-    fetch(first + UNR, xn, en);
-    eval(first, x, e);
-    pipeline_entry_fence();
-    for (int i = first + UNR; i < last; i += UNR) {
+    if constexpr (DEG <= 16) {
+        uint32_t x[UNR][DEG], xn[UNR][DEG];
+        int e[UNR][DEG], en[UNR][DEG];
+        fetch(first, x, e);
+        fetch(first + UNR, xn, en);
+        eval(first, x, e);
+        pipeline_entry_fence();
+        for (int i = first + UNR; i < last; i += UNR) {
 #pragma unroll
-        for (int u = 0; u < UNR; u++)
+            for (int u = 0; u < UNR; u++)
 #pragma unroll
-            for (int k = 0; k < DEG; k++) { x[u][k] = xn[u][k]; e[u][k] = en[u][k]; }
-        fetch(i + UNR, xn, en);
-        eval(i, x, e);
+                for (int k = 0; k < DEG; k++) { x[u][k] = xn[u][k]; e[u][k] = en[u][k]; }
+            fetch(i + UNR, xn, en);
+            eval(i, x, e);
+        }
+    } else {
+        // wide checks: a second set of rows in flight would cost DEG more registers per lane than the
+        // occupancy it buys; the DEG loads of one check already cover the latency
+        for (int i = first; i < last; i += UNR) {
+            uint32_t x[UNR][DEG];
+            int e[UNR][DEG];
+            fetch(i, x, e);
+            eval(i, x, e);
+        }
     }
     if (P.check) {
         uint32_t fail[PACK];
@@ -440,9 +451,19 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
 // work on every CU: blocks are handed to roles (degree class x pass kind x half) through an
 // interleaved item table, each block stays homogeneous (one role) so its tables sit at LDS offset 0.
 constexpr int kFusedMaxRoles = 10;
-constexpr int kFusedMaxVnDeg = 8;      // degrees instantiated in the fused kernel (register budget:
-constexpr int kFusedMaxCnDeg = 8;      //  the kernel's VGPR count is the maximum over all cases)
-constexpr int kFusedMaxTables = 8;
+constexpr int kFusedMaxTables = 20;
+// Degree buckets of the fused kernel.  Its register count is the maximum over all the cases it contains
+// (every degree up to the bucket limits), so codes with small degrees get their own, leaner instantiation:
+//   bucket 0: variable degrees <= 8,  check degrees <= 8   (64 VGPRs, 8 waves per SIMD)
+//   bucket 1:                  <= 12,               <= 16
+//   bucket 2:                  <= 20,               <= 32
+constexpr int kFusedBuckets = 3;
+constexpr int kFusedVnDeg[kFusedBuckets] = {8, 12, 20};
+constexpr int kFusedCnDeg[kFusedBuckets] = {8, 16, 32};
+inline int fused_bucket(int max_vn_deg, int max_cn_deg) {
+    for (int b = 0; b < kFusedBuckets; b++) if (max_vn_deg <= kFusedVnDeg[b] && max_cn_deg <= kFusedCnDeg[b]) return b;
+    return -1;
+}
 
 struct RoleParams {
     int32_t kind;          // 0: min-sum check class, 1: variable class
@@ -472,20 +493,25 @@ __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, 
 }
 
 // items[b] = {role, block index within the role}
-template <int PACK, bool CHECK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void pass_fused_kernel(
+template <int PACK, bool CHECK, int BUCKET>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? 7 : BUCKET == 1 ? 4 : 3, 8))) void pass_fused_kernel(
     FusedParams FP, const int2 *__restrict__ items, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[kFusedMaxTables * kFastTableStride];
+    constexpr int MAXVN = kFusedVnDeg[BUCKET], MAXCN = kFusedCnDeg[BUCKET];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_tab[MAXVN * kFastTableStride];
     const int2 it = items[blockIdx.x];
     const int r = __builtin_amdgcn_readfirstlane(it.x), rb = __builtin_amdgcn_readfirstlane(it.y);
-    const RoleParams &P = FP.role[r];
+    // the role is picked with a run-time index: read it straight from the kernel-argument segment (scalar
+    // loads from constant memory) -- indexing the by-value struct would make the compiler copy all of it
+    // to scratch memory first
+    const FusedParams *kernarg = (const FusedParams *)__builtin_amdgcn_kernarg_segment_ptr();    // FP is the first argument
+    const RoleParams &P = kernarg->role[r];
     if (FP.prio && P.kind) {                       // LUT-heavy waves first: they are the long ones
         if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     }
-    if (P.kind == 0) fused_cn_switch<PACK>(P, rb, std::make_integer_sequence<int, kFusedMaxCnDeg - 1>{}, msgs, state_w, vfail_w, fast_idx);
-    else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, kFusedMaxVnDeg>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+    if (P.kind == 0) fused_cn_switch<PACK>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx);
+    else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -634,17 +660,18 @@ bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int
 }
 
 // skewed pipeline: one launch of pass_fused_kernel over n_blocks items
-template <int PACK>
+template <int PACK, int BUCKET>
 void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, int n_blocks, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
                   const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     if (vn_check)
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, true>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, true, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
                            state_w, vfail_w, tables, fast_idx);
     else
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, false>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, false, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
                            state_w, vfail_w, tables, fast_idx);
 }
 
+#define LUTLDPC_FUSED_SIG (hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *)
 #define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
     X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
     X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
@@ -652,7 +679,8 @@ void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, in
     X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
     X template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
     X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
-    X template void launch_fused<1>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
-    X template void launch_fused<2>(hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *);
+    X template void launch_fused<1, 0> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 0> LUTLDPC_FUSED_SIG; \
+    X template void launch_fused<1, 1> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 1> LUTLDPC_FUSED_SIG; \
+    X template void launch_fused<1, 2> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 2> LUTLDPC_FUSED_SIG;
 
 }  // namespace lutldpc
