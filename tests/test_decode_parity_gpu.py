@@ -89,6 +89,20 @@ def test_skewed_pipeline(name, B, snr, env, monkeypatch):
     dec.close()
 
 
+def test_graph_replay_of_repeated_decodes():
+    """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
+    and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size
+    that forces bigger buffers (captured addresses become stale) and a return to the first size."""
+    cd = oracle_codec("reg36_n1000_q4")
+    dec = product_decoder(cd)
+    for rep, (B, psc, pisc) in enumerate([(600, True, True), (600, True, True), (600, True, True), (600, False, False), (600, False, False),
+                                          (600, False, False), (1300, True, False), (1300, True, False), (1300, True, False), (600, True, True),
+                                          (600, True, True), (600, True, True)]):
+        cha, msg, _ = awgn_labels(cd, B, 2.0, seed=900 + rep)
+        _compare(cd, dec, cha, msg, psc, pisc)
+    dec.close()
+
+
 @pytest.mark.parametrize("B", [1, 3, 255, 256, 257, 511, 512, 513])
 def test_batch_sizes(B):
     cd = oracle_codec("n500_q4_i8")
