@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- decoded codewords/s of the MI355X LUT-LDPC decode path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dvbs2|twin|c2|c1|c5] [--batch B] [--mode fixed|shipped]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dvbs2|twin|c2|c1|c5|c5chk] [--batch B] [--mode fixed|shipped]
 
 A *step* is one pass of the hot path (LDPC_Code_LUT::lut_decode, all iterations) over one batch of
 B frames per GPU whose quantised labels are already resident in HBM.  Default workload: the
@@ -43,10 +43,15 @@ WORKLOADS = {
     "twin": ("rate0.50_dv02-08_dc07-08_lut_q4_N64800", 0.88, 50, 4, 4, 4096, {}, 32400),
     "c2": ("rate0.50_dv03_dc06_N10000", 0.84, 50, 4, 4, 4096, {}, 5000),
     "c1": ("rate0.50_dv02-17_dc08-09_lut_q4_N500", 0.88, 50, 4, 4, 16384, {}, 250),
+    # params/ber.ini.regular.example: (6,32) N=2048, rank 325, 3-bit messages, 8 iterations, trees from a file, QCHA
+    # initial messages, design at Eb/N0 = 3.9 dB (sigma^2 = 1 / (2 R 10^0.39)); c5chk: CHKTREE check update (min_lut = false)
+    "c5": ("rate0.84_reg_v6c32_N2048", 0.6159, 8, 4, 3, 32768, dict(tree_method="filename=" + str(ROOT / "data" / "trees" / "6_32_wide.ini")), 325),
+    "c5chk": ("rate0.84_reg_v6c32_N2048", 0.6159, 8, 4, 3, 32768,
+              dict(tree_method="filename=" + str(ROOT / "data" / "trees" / "6_32_wide.ini"), min_lut=False), 325),
 }
 
 
-def make_labels(cd, B, snr_db, seed):
+def make_labels(cd, B, snr_db, seed, qcha_map=None):
     """All-zero codeword over BPSK/AWGN (src/LDPC_BER_Sim.cpp:248-278) quantised with the designed
     boundaries; generated on the host once, outside the timed region."""
     rng = np.random.default_rng(seed)
@@ -60,7 +65,10 @@ def make_labels(cd, B, snr_db, seed):
         llr = 4 * x / N0
         # quant_nonlin: number of boundaries strictly below the value (src/common.cpp:120-129)
         cha[b0:b0 + len(llr)] = np.searchsorted(qc, llr, side="left").astype(np.uint8)
-        msg[b0:b0 + len(llr)] = np.searchsorted(qm, llr, side="left").astype(np.uint8)
+        if qcha_map is None:
+            msg[b0:b0 + len(llr)] = np.searchsorted(qm, llr, side="left").astype(np.uint8)
+        else:                       # QCHA: initial message = Nq_Cha_2_Nq_Msg_map[channel label] (src/LDPC_Code_LUT.cpp:216-220)
+            msg[b0:b0 + len(llr)] = qcha_map[cha[b0:b0 + len(llr)]]
     return cha, msg
 
 
@@ -71,7 +79,7 @@ def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=15.0):
     code = orc.Code(ROOT / "data" / "codes" / f"{cd.alist}.alist")
     oc = orc.Codec(code, skip_rank=True)
     nq = np.full(max_iter, cd.nq_msg, np.int32)
-    oc.set_trees_txt(cd.var_trees_txt, "", max_iter, np.zeros(max_iter, np.uint8), cd.nq_cha, nq, True)
+    oc.set_trees_txt(cd.var_trees_txt, "" if cd.min_lut else cd.chk_trees_txt, max_iter, np.zeros(max_iter, np.uint8), cd.nq_cha, nq, cd.min_lut)
     oc.set_exit_conditions(max_iter, psc, psc)
     t0 = time.perf_counter()
     oc.lut_decode_batch(cha[:1], msg[:1])
@@ -119,17 +127,23 @@ def main():
     alist, sigma, max_iter, qc, qm, B_default, extra, known_rank = WORKLOADS[args.workload]
     B = args.batch or B_default
     psc = args.mode == "shipped"
-    snr = args.snr if args.snr is not None else (-10 * np.log10(2 * 0.5 * sigma * sigma) if not psc else 1.5)
 
     # ---- set-up (untimed): alist -> design LUTs by density evolution -> HIP decoder --------------
     cd = L.Codec(ROOT / "data" / "codes" / f"{alist}.alist", known_rank=known_rank, device=local)
     cd.alist, cd.nq_cha, cd.nq_msg = alist, 1 << qc, 1 << qm
     cd.design_luts(sigma2=sigma * sigma, max_iters=max_iter, nq_cha=1 << qc, nq_msg=1 << qm, **extra)
     cd.set_exit_conditions(max_iter, psc, psc)
+    cd.min_lut = bool(extra.get("min_lut", True))
+    # fixed work: the design point itself (sigma^2 = N0/2, N0 = 10^(-snr/10)/R); as shipped: a point where frames converge
+    snr = args.snr if args.snr is not None else (-10 * np.log10(2 * cd.rate * sigma * sigma) + (0.0 if not psc else 0.4))
     dec = cd.decoder()
     N, E, I = cd.nvar, cd.nedges, max_iter
 
-    cha_h, msg_h = make_labels(cd, B, snr, seed=1234 + rank)
+    qcha_map = None
+    if args.workload.startswith("c5"):
+        cd.set_initial_message_mode(1)
+        qcha_map = np.asarray(cd.cha2msg_map, np.uint8)
+    cha_h, msg_h = make_labels(cd, B, snr, seed=1234 + rank, qcha_map=qcha_map)
     cha = torch.from_numpy(cha_h).cuda()
     msg = torch.from_numpy(msg_h).cuda()
     out_bits = torch.empty((B, N), dtype=torch.uint8, device="cuda")

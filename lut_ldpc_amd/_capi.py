@@ -54,6 +54,7 @@ _SIGNATURES = {
     "lutldpc_decoder_describe": (_cp, [_vp]),
     "lutldpc_selftest_program_eval": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int]),
     "lutldpc_selftest_program_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),
+    "lutldpc_selftest_jit_source": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
     if hasattr(lib, _name):

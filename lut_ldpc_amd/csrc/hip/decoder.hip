@@ -10,6 +10,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_frontend.hpp"
 #include "lut_program.hpp"
+#include "jit.hpp"
 
 namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast_*.hip / fused.hip
 
@@ -118,6 +119,10 @@ struct lutldpc_decoder {
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
     int vn_edges_per_wave = 32, cn_edges_per_wave = 56;
     int fused_prio = 0;
+    int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
+    std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
+    std::vector<std::vector<const JitKernel *>> var_jit, dec_jit;     // [set][class], null = none
+    std::string jit_log;                                               // last hiprtc diagnostic (describe())
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
     std::map<std::array<int, 4>, GraphSlot> graphs;       // key {B, psc, pisc, max_iters}
@@ -301,6 +306,41 @@ int compile_all(lutldpc_decoder *d) {
     return LUTLDPC_OK;
 }
 
+// is class i of a pass handled by a compile-time specialised kernel?
+bool fast_covers(const lutldpc_decoder *d, const std::vector<FastClassPlan> &fast, size_t i) {
+    return d->use_fast && i < fast.size() && fast[i].ok && fast[i].P.deg <= kFastMaxDeg;
+}
+
+// jit.hpp: generate + compile + load a kernel for every variable / decision class without one
+void build_jit(lutldpc_decoder *d) {
+    const size_t ns = d->var_plan.size();
+    d->var_jit.assign(ns, {}); d->dec_jit.assign(ns, {});
+    if (!d->use_jit || !d->use_fast) return;
+    for (size_t s = 0; s < ns; s++)
+        for (int kind : {TT_VAR, TT_DEC}) {
+            const PassPlan &plan = kind == TT_VAR ? d->var_plan[s] : d->dec_plan[s];
+            if (!plan.valid) continue;
+            const auto &progs = kind == TT_VAR ? d->var_prog[s] : d->dec_prog[s];
+            const auto &fast = kind == TT_VAR ? d->var_fast[s] : d->dec_fast[s];
+            auto &out = kind == TT_VAR ? d->var_jit[s] : d->dec_jit[s];
+            out.assign(d->vclass.size(), nullptr);
+            for (size_t i = 0; i < d->vclass.size(); i++) {
+                if (fast_covers(d, fast, i)) continue;
+                std::string src, err;
+                if (!jit_vn_source(progs[i], kind, d->vclass[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err)) { d->jit_log = err; continue; }
+                auto it = d->jit_cache.find(src);
+                if (it == d->jit_cache.end()) {
+                    std::vector<char> code;
+                    JitKernel k;
+                    std::string log;
+                    if (!jit_compile(src, code, log) || !jit_load(code, k, log)) { d->jit_log = log; d->jit_cache[src] = JitKernel(); continue; }
+                    it = d->jit_cache.emplace(src, k).first;
+                }
+                if (it->second.ok()) out[i] = &it->second;
+            }
+        }
+}
+
 int upload_static(lutldpc_decoder *d) {
     HIP_TRY(hipSetDevice(d->device));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
@@ -323,6 +363,7 @@ int upload_static(lutldpc_decoder *d) {
         t.resize((t.size() + 3) / 4 * 4 + 16, 0);
         HIP_TRY(d->d_tables.upload(t));
     }
+    build_jit(d);
     return LUTLDPC_OK;
 }
 
@@ -414,7 +455,7 @@ PassParams filter_params(const PassParams &P, const std::vector<char> &keep) {
 }
 
 template <int KIND>
-int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPlan> *fast, int G, int nz, int check, int write_hard, int kind_id) {
+int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPlan> *fast, const std::vector<const JitKernel *> *jit, int G, int nz, int check, int write_hard, int kind_id) {
     if (!plan.valid) return fail(LUTLDPC_ERR_STATE, "pass plan missing for this tree set");
     Timed t(d, kind_id);
     PassParams P = plan.P;
@@ -430,6 +471,26 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
                                      reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
                                      d->d_fast_idx.p, d->E, d->nvar, d->Bcap / 4));
             if (ok) keep[(size_t)i] = 0;
+        }
+    // run-time generated kernels (jit.hpp) for the other variable / decision classes
+    if (jit && KIND != TT_CHK)
+        for (int i = 0; i < P.n_seg && (size_t)i < jit->size(); i++) {
+            const JitKernel *k = (*jit)[(size_t)i];
+            if (!keep[(size_t)i] || !k) continue;
+            FastParams F{};
+            F.n_nodes = P.seg[i].n_nodes; F.idx_off = d->vn_idx_off[(size_t)i]; F.deg = P.seg[i].deg;
+            F.nodes_per_wave = d->npw_vn(F.deg); F.waves_per_group = (F.n_nodes + F.nodes_per_wave - 1) / F.nodes_per_wave;
+            F.G = G; F.E = d->E; F.N = d->nvar; F.g0 = 0; F.nz = nz; F.check = check; F.write_hard = write_hard; F.vfail_stride_w = d->Bcap / 4;
+            F.tab_off[0] = P.seg[i].tab_off; F.tab_len[0] = P.seg[i].tab_bytes;
+            uint8_t *msgs = d->d_msgs.p, *hard = d->d_hard.p;
+            const uint8_t *cha = d->d_cha_t.p, *tables = d->d_tables.p;
+            const uint32_t *state_w = reinterpret_cast<const uint32_t *>(d->d_state.p);
+            uint32_t *vfail_w = reinterpret_cast<uint32_t *>(d->d_vfail.p);
+            const int32_t *fidx = d->d_fast_idx.p;
+            void *args[] = {&F, &msgs, &cha, &hard, &state_w, &vfail_w, &tables, &fidx};
+            const unsigned blocks = (unsigned)((F.waves_per_group * G + 3) / 4);
+            HIP_TRY(hipModuleLaunchKernel(k->fn, blocks, 1, 1, 256, 1, 1, 0, d->stream, args, nullptr));
+            keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
     if (any) {
@@ -638,17 +699,17 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
         const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
         if (d->min_lut) rc = launch_cn_minsum(d, G, nz_in, chk_check);
-        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
+        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, nullptr, G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
         if (rc) return rc;
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
         if (ii != I - 1) {
             const int nz_out = d->Nq_Msg[(size_t)(ii + 1)] / 2;
-            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
+            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], d->var_jit.empty() ? nullptr : &d->var_jit[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
             if (rc) return rc;
         }
     }
     // :340-349
-    if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
+    if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], d->dec_jit.empty() ? nullptr : &d->dec_jit[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
     if ((rc = launch_syndrome(d, G))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
     if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
@@ -756,7 +817,7 @@ void make_describe(lutldpc_decoder *d) {
     for (size_t i = 0; i < d->vclass.size(); i++) {
         const bool f = d->use_fast && !d->var_fast.empty() && i < d->var_fast[0].size() && d->var_fast[0][i].ok && d->vclass[i].deg <= kFastMaxDeg;
         o << (i ? "," : "") << "{\"deg\":" << d->vclass[i].deg << ",\"nodes\":" << d->vclass[i].nodes.size() << ",\"kernel\":\""
-          << (f ? "vn_balanced_fast_kernel" : "tree_pass_kernel<VAR>") << "\"}";
+          << (f ? "vn_balanced_fast_kernel" : (!d->var_jit.empty() && i < d->var_jit[0].size() && d->var_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<VAR>") << "\"}";
     }
     o << "],\"cn_classes\":[";
     for (size_t i = 0; i < d->cclass.size(); i++) {
@@ -844,6 +905,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     d->nodes_per_wave_cn = d->nodes_per_wave;
     if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
@@ -876,6 +938,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();
+        for (auto &kv : d->jit_cache) kv.second.release();
         for (auto &kv : d->item_tabs) kv.second->release();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -1060,6 +1123,22 @@ int lutldpc_selftest_program_stats(lutldpc_decoder *d, int kind, int set, int cl
     if (n_ops_naive) *n_ops_naive = p->n_ops_naive;
     if (n_slots) *n_slots = p->n_slots;
     return LUTLDPC_OK;
+}
+
+int64_t lutldpc_selftest_jit_source(lutldpc_decoder *d, int kind, int set, int cls, char *buf, int64_t cap, int compile) {
+    if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
+    const Program *p = find_prog(d, kind, set, cls);
+    if (!p || (kind != TT_VAR && kind != TT_DEC) || cls < 0 || (size_t)cls >= d->vclass.size()) return fail(LUTLDPC_ERR_ARG, "no such variable / decision program");
+    const PassPlan &plan = kind == TT_VAR ? d->var_plan[(size_t)set] : d->dec_plan[(size_t)set];
+    std::string src, err;
+    if (!jit_vn_source(*p, kind, d->vclass[(size_t)cls].deg, d->pack, plan.P.seg[cls].tab_bytes, src, err)) return fail(LUTLDPC_ERR_UNSUPPORTED, err);
+    if (compile) {
+        std::vector<char> code;
+        std::string log;
+        if (!jit_compile(src, code, log)) return fail(LUTLDPC_ERR_HIP, "hiprtc: " + log);
+    }
+    if (buf && cap > (int64_t)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+    return (int64_t)src.size() + 1;
 }
 
 }  // extern "C"

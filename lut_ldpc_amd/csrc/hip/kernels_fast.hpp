@@ -19,26 +19,6 @@
 
 namespace lutldpc {
 
-constexpr int kFastMaxTables = 32;     // LUT nodes of one balanced tree (degree <= 33)
-constexpr int kFastTableStride = 256;  // bytes per table slot in LDS (byte tables; nibble tables use the first half)
-
-struct FastParams {
-    int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;
-    int32_t idx_off;       // offset of the class in the dense index blob (see decoder.hip: build_fast_index)
-    int32_t G, E, N;
-    int32_t g0;            // first frame group of the launch (the G groups g0 .. g0+G-1 are processed)
-    int32_t nz;            // sign threshold (see PassParams)
-    int32_t shift_msg;     // log2 of the message alphabet feeding the tables (label = a | b << shift)
-    int32_t check, write_hard;
-    int32_t deg;
-    int32_t n_tables;
-    int32_t tab_off[kFastMaxTables];    // byte offsets into the table blob, canonical node order
-    int32_t tab_len[kFastMaxTables];
-    int32_t tab_shift[kFastMaxTables];  // log2 alphabet of each table's first child
-    int32_t nib;                        // (unused: nibble-packed LDS tables were measured slower and removed)
-    int32_t vfail_stride_w;             // words between two copies of the early-termination flags (see flag_frames)
-};
-
 // ------------------------------------------------------------------------------------------
 // Min-sum check pass.  DMAX: register budget (rows kept per check); the true degree is the
 // wave-uniform runtime value P.deg <= DMAX.  One wave = one 256-byte row; UNR checks are in flight.
@@ -250,12 +230,6 @@ struct Bal {
 // The label is formed by an explicit v_lshl_or_b32: written as `a | (b << sh)` the compiler hoists the
 // shared shift `b << sh` of a value that feeds several variants and ends up with MORE instructions
 // (one shift per value plus one OR per label instead of one fused op per label).
-// (x << s) | y in one instruction, s wave-uniform
-__device__ __forceinline__ uint32_t lshl_or(uint32_t x, int s, uint32_t y) {
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(y));
-    return r;
-}
 __device__ __forceinline__ uint32_t lut1(const uint8_t *lds_tab, int t, uint32_t a, uint32_t b, int sh) {
     return lds_tab[t * kFastTableStride + lshl_or(b, sh, a)];
 }

@@ -108,6 +108,15 @@ class Decoder:
     def describe(self) -> dict:
         return json.loads(lib.lutldpc_decoder_describe(self._h).decode())
 
+    def jit_source(self, kind: int, tree_set: int, cls: int, compile: bool = False) -> str:
+        """HIP source generated for a variable (0) / decision (2) class; compile=True also runs hiprtc (no GPU needed)."""
+        n = lib.lutldpc_selftest_jit_source(self._h, kind, tree_set, cls, None, 0, int(compile))
+        if n < 0:
+            check(int(n))
+        buf = C.create_string_buffer(n)
+        lib.lutldpc_selftest_jit_source(self._h, kind, tree_set, cls, buf, n, 0)
+        return buf.value.decode()
+
     # ---- compile-step self test (host only) ----------------------------------------------------
     def program_eval(self, kind: int, tree_set: int, cls: int, inputs, n_out: int):
         a = _i32(inputs)

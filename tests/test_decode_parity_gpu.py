@@ -89,6 +89,29 @@ def test_skewed_pipeline(name, B, snr, env, monkeypatch):
     dec.close()
 
 
+@pytest.mark.parametrize("name", ["c5_minlut", "reg36_n1000_rootonly", "reg36_n1000_high", "reg36_n1000_q5"])
+def test_generated_kernels_are_used_and_match(name, monkeypatch):
+    """jit.hpp: the kernel generated from the node program vs the oracle, and vs the interpreter (LUTLDPC_JIT=0)."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    # (degree 3: auto_bin_high over two message leaves IS the balanced shape -> compile-time kernel)
+    jit_expected = name != "reg36_n1000_high"
+    assert dec.describe()["vn_classes"][0]["kernel"] == ("lutldpc_jit_pass" if jit_expected else "vn_balanced_fast_kernel"), dec.describe()
+    mode = 1 if name.startswith("c5") else 0
+    cha, msg, _ = awgn_labels(cd, 700, 4.0 if name.startswith("c5") else 2.2, seed=31, mode=mode)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, False, False)
+    got = dec.lut_decode_batch(cha, msg)
+    dec.close()
+    monkeypatch.setenv("LUTLDPC_JIT", "0")
+    ref = product_decoder(cd)
+    assert ref.describe()["vn_classes"][0]["kernel"] == ("tree_pass_kernel<VAR>" if jit_expected else "vn_balanced_fast_kernel")
+    ref.set_exit_conditions(cd.max_iters, False, False)
+    want = ref.lut_decode_batch(cha, msg)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    ref.close()
+
+
 def test_graph_replay_of_repeated_decodes():
     """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
     and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size

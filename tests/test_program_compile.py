@@ -72,3 +72,26 @@ def test_create_rejects_bad_input():
     with pytest.raises(L.LutLdpcError):            # iteration 3 is not a decision-tree set
         d.set_exit_conditions(3)
     d.close()
+
+
+@pytest.mark.parametrize("name", ["c5_minlut", "reg36_n1000_rootonly", "reg36_n1000_high", "reg36_n1000_q5"])
+def test_jit_source_compiles_without_a_gpu(name):
+    """Tree shapes outside the compile-time path (file trees, root_only, auto_bin_high, 5-bit alphabets) get a
+    kernel generated from their node program; hiprtc cross-compiles it for gfx950 here, it runs in the gpu tests."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)
+    src = dec.jit_source(0, 0, 0, compile=True)
+    stats = dec.program_stats(0, 0, 0)
+    assert src.count("= tab[") == stats["ops"]                  # one statement per look-up of the shared program
+    assert "lutldpc_jit_pass" in src and "pipeline_entry_fence" in src
+    last = max(s for s in range(cd.max_iters) if _has_dec(dec, s))
+    assert "hardw = lshl_or(" in dec.jit_source(2, last, 0, compile=True)
+    dec.close()
+
+
+def _has_dec(dec, s):
+    try:
+        dec.program_stats(2, s, 0)
+        return True
+    except Exception:
+        return False
