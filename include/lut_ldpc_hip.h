@@ -179,7 +179,7 @@ int lutldpc_selftest_program_eval(lutldpc_decoder *d, int kind, int set, int cls
 int lutldpc_selftest_program_stats(lutldpc_decoder *d, int kind, int set, int cls,
                                    int32_t *n_ops, int32_t *n_ops_naive, int32_t *n_slots);
 
-/* The HIP source jit.hpp generates for a variable (kind 0) / decision (kind 2) class -- copied into buf when
+/* The HIP source jit.hpp generates for a variable (kind 0) / CHKTREE check (kind 1) / decision (kind 2) class -- copied into buf when
  * cap suffices; returns the length needed including the terminator, < 0 on error.  With compile != 0 the
  * source is also compiled for gfx950 with hiprtc (no device needed); a failure returns LUTLDPC_ERR_HIP and
  * leaves the compiler log in lutldpc_last_error(). */

@@ -121,7 +121,7 @@ struct lutldpc_decoder {
     int fused_prio = 0;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
-    std::vector<std::vector<const JitKernel *>> var_jit, dec_jit;     // [set][class], null = none
+    std::vector<std::vector<const JitKernel *>> var_jit, dec_jit, chk_jit;     // [set][class], null = none
     std::string jit_log;                                               // last hiprtc diagnostic (describe())
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
@@ -311,23 +311,27 @@ bool fast_covers(const lutldpc_decoder *d, const std::vector<FastClassPlan> &fas
     return d->use_fast && i < fast.size() && fast[i].ok && fast[i].P.deg <= kFastMaxDeg;
 }
 
-// jit.hpp: generate + compile + load a kernel for every variable / decision class without one
+// jit.hpp: generate + compile + load a kernel for every variable / decision / CHKTREE class without a
+// compile-time specialised one
 void build_jit(lutldpc_decoder *d) {
     const size_t ns = d->var_plan.size();
-    d->var_jit.assign(ns, {}); d->dec_jit.assign(ns, {});
+    d->var_jit.assign(ns, {}); d->dec_jit.assign(ns, {}); d->chk_jit.assign(ns, {});
     if (!d->use_jit || !d->use_fast) return;
     for (size_t s = 0; s < ns; s++)
-        for (int kind : {TT_VAR, TT_DEC}) {
-            const PassPlan &plan = kind == TT_VAR ? d->var_plan[s] : d->dec_plan[s];
+        for (int kind : {TT_VAR, TT_DEC, TT_CHK}) {
+            if (kind == TT_CHK && d->min_lut) continue;
+            const PassPlan &plan = kind == TT_VAR ? d->var_plan[s] : kind == TT_DEC ? d->dec_plan[s] : d->chk_plan[s];
             if (!plan.valid) continue;
-            const auto &progs = kind == TT_VAR ? d->var_prog[s] : d->dec_prog[s];
-            const auto &fast = kind == TT_VAR ? d->var_fast[s] : d->dec_fast[s];
-            auto &out = kind == TT_VAR ? d->var_jit[s] : d->dec_jit[s];
-            out.assign(d->vclass.size(), nullptr);
-            for (size_t i = 0; i < d->vclass.size(); i++) {
-                if (fast_covers(d, fast, i)) continue;
+            const auto &progs = kind == TT_VAR ? d->var_prog[s] : kind == TT_DEC ? d->dec_prog[s] : d->chk_prog[s];
+            const auto &cls = kind == TT_CHK ? d->cclass : d->vclass;
+            auto &out = kind == TT_VAR ? d->var_jit[s] : kind == TT_DEC ? d->dec_jit[s] : d->chk_jit[s];
+            out.assign(cls.size(), nullptr);
+            for (size_t i = 0; i < cls.size(); i++) {
+                if (kind != TT_CHK && fast_covers(d, kind == TT_VAR ? d->var_fast[s] : d->dec_fast[s], i)) continue;
                 std::string src, err;
-                if (!jit_vn_source(progs[i], kind, d->vclass[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err)) { d->jit_log = err; continue; }
+                const bool gen = kind == TT_CHK ? jit_cn_source(progs[i], cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err)
+                                                : jit_vn_source(progs[i], kind, cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err);
+                if (!gen) { d->jit_log = err; continue; }
                 auto it = d->jit_cache.find(src);
                 if (it == d->jit_cache.end()) {
                     std::vector<char> code;
@@ -472,14 +476,15 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
                                      d->d_fast_idx.p, d->E, d->nvar, d->Bcap / 4));
             if (ok) keep[(size_t)i] = 0;
         }
-    // run-time generated kernels (jit.hpp) for the other variable / decision classes
-    if (jit && KIND != TT_CHK)
+    // run-time generated kernels (jit.hpp) for the classes without a compile-time one
+    if (jit)
         for (int i = 0; i < P.n_seg && (size_t)i < jit->size(); i++) {
             const JitKernel *k = (*jit)[(size_t)i];
             if (!keep[(size_t)i] || !k) continue;
             FastParams F{};
-            F.n_nodes = P.seg[i].n_nodes; F.idx_off = d->vn_idx_off[(size_t)i]; F.deg = P.seg[i].deg;
-            F.nodes_per_wave = d->npw_vn(F.deg); F.waves_per_group = (F.n_nodes + F.nodes_per_wave - 1) / F.nodes_per_wave;
+            F.n_nodes = P.seg[i].n_nodes; F.deg = P.seg[i].deg;
+            F.idx_off = KIND == TT_CHK ? d->cn_idx_off[(size_t)i] : d->vn_idx_off[(size_t)i];
+            F.nodes_per_wave = KIND == TT_CHK ? d->npw_cn(F.deg) : d->npw_vn(F.deg); F.waves_per_group = (F.n_nodes + F.nodes_per_wave - 1) / F.nodes_per_wave;
             F.G = G; F.E = d->E; F.N = d->nvar; F.g0 = 0; F.nz = nz; F.check = check; F.write_hard = write_hard; F.vfail_stride_w = d->Bcap / 4;
             F.tab_off[0] = P.seg[i].tab_off; F.tab_len[0] = P.seg[i].tab_bytes;
             uint8_t *msgs = d->d_msgs.p, *hard = d->d_hard.p;
@@ -699,7 +704,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
         const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
         if (d->min_lut) rc = launch_cn_minsum(d, G, nz_in, chk_check);
-        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, nullptr, G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
+        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, d->chk_jit.empty() ? nullptr : &d->chk_jit[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
         if (rc) return rc;
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
         if (ii != I - 1) {
@@ -823,7 +828,8 @@ void make_describe(lutldpc_decoder *d) {
     for (size_t i = 0; i < d->cclass.size(); i++) {
         const bool f = d->use_fast && d->min_lut && d->cclass[i].deg >= 2 && d->cclass[i].deg <= kFastMaxCnDeg && is_pow2(d->Nq_Msg[0] / 2);
         o << (i ? "," : "") << "{\"deg\":" << d->cclass[i].deg << ",\"nodes\":" << d->cclass[i].nodes.size() << ",\"kernel\":\""
-          << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel") : "tree_pass_kernel<CHK>") << "\"}";
+          << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
+                         : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
     o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << "}";
     d->describe = o.str();
@@ -1128,10 +1134,12 @@ int lutldpc_selftest_program_stats(lutldpc_decoder *d, int kind, int set, int cl
 int64_t lutldpc_selftest_jit_source(lutldpc_decoder *d, int kind, int set, int cls, char *buf, int64_t cap, int compile) {
     if (!d) return fail(LUTLDPC_ERR_ARG, "NULL decoder");
     const Program *p = find_prog(d, kind, set, cls);
-    if (!p || (kind != TT_VAR && kind != TT_DEC) || cls < 0 || (size_t)cls >= d->vclass.size()) return fail(LUTLDPC_ERR_ARG, "no such variable / decision program");
-    const PassPlan &plan = kind == TT_VAR ? d->var_plan[(size_t)set] : d->dec_plan[(size_t)set];
+    if (!p) return fail(LUTLDPC_ERR_ARG, "no such program");
+    const PassPlan &plan = kind == TT_VAR ? d->var_plan[(size_t)set] : kind == TT_DEC ? d->dec_plan[(size_t)set] : d->chk_plan[(size_t)set];
     std::string src, err;
-    if (!jit_vn_source(*p, kind, d->vclass[(size_t)cls].deg, d->pack, plan.P.seg[cls].tab_bytes, src, err)) return fail(LUTLDPC_ERR_UNSUPPORTED, err);
+    const bool gen = kind == TT_CHK ? jit_cn_source(*p, d->cclass[(size_t)cls].deg, d->pack, plan.P.seg[cls].tab_bytes, src, err)
+                                    : jit_vn_source(*p, kind, d->vclass[(size_t)cls].deg, d->pack, plan.P.seg[cls].tab_bytes, src, err);
+    if (!gen) return fail(LUTLDPC_ERR_UNSUPPORTED, err);
     if (compile) {
         std::vector<char> code;
         std::string log;

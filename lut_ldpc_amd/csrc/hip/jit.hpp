@@ -170,6 +170,139 @@ inline bool jit_vn_source(const Program &prog, int kind, int deg, int pack, int 
     return true;
 }
 
+// Source of the CHKTREE check pass of one degree class (min_lut = false, src/LDPC_Code_LUT.cpp:416-426,
+// src/LUT_Tree.cpp:792-807,420-445).  Every value is used as (sign, magnitude): label = sum of the
+// children's magnitudes times their place values, the parity of the children's signs selects the half of
+// the expanded table (lut_program.hpp: expand_table).  The kernel skeleton is cn_minsum_body's.
+inline bool jit_cn_source(const Program &prog, int deg, int pack, int tab_bytes, std::string &src, std::string &err)
+{
+    if (prog.kind != TT_CHK || prog.n_in != deg || prog.n_out != deg) { err = "not a check program of this degree"; return false; }
+    const int bits = 8 / pack;
+    const bool in_lds = tab_bytes <= kJitMaxLdsTable;
+    const int tab_pad = (tab_bytes + 15) / 16 * 16;
+    const bool pipe = deg <= 16;
+    std::ostringstream o;
+    o << kCommonHeaderText << "\nusing namespace lutldpc;\n"
+      << "extern \"C\" __global__ __launch_bounds__(256) void lutldpc_jit_pass(FastParams P, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,\n"
+      << "    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)\n{\n"
+      << "    constexpr int PACK = " << pack << ", DEG = " << deg << ", F = 4 * PACK, BITS = " << bits << ";\n    (void)cha; (void)hard;\n";
+    if (in_lds) {
+        o << "    __shared__ __attribute__((aligned(16))) uint8_t tab[" << tab_pad << "];\n"
+          << "    {\n        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[0]);\n"
+          << "        for (int i = threadIdx.x; i < " << tab_pad / 4 << "; i += 256) reinterpret_cast<uint32_t *>(tab)[i] = src[i];\n    }\n"
+          << "    __syncthreads();\n";
+    } else {
+        o << "    const uint8_t *tab = tables + P.tab_off[0];\n";
+    }
+    o << R"SRC(    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int gl = wave / P.waves_per_group;
+    if (gl >= P.G) return;
+    const int chunk = wave - gl * P.waves_per_group;
+    const int g = gl + P.g0;
+    uint32_t amask[PACK];
+    if (load_active<PACK>(state_w, g, lane, amask)) return;
+    const uint32_t smask = pack_masks<PACK>(amask);
+    const rsrc_t base = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const int32_t *edges = fast_idx + P.idx_off;                // dense [n_nodes][DEG] edge ids
+    const int first = chunk * P.nodes_per_wave;
+    int last = first + P.nodes_per_wave;
+    if (last > P.n_nodes) last = P.n_nodes;
+    const uint32_t nz = (uint32_t)P.nz;
+    const bool chk = P.check != 0;
+    uint32_t failw = 0;
+    auto fetch = [&](int i, uint32_t (&xx)[DEG], int (&ee)[DEG]) {
+        const int ii = i < last ? i : last - 1;
+#pragma unroll
+        for (int k = 0; k < DEG; k++) ee[k] = edges[(size_t)ii * DEG + k];
+        const uint32_t off = lane4 | (i < last ? 0u : 0x80000000u);
+#pragma unroll
+        for (int k = 0; k < DEG; k++) xx[k] = ld_row(base, (uint32_t)ee[k] * kRowBytes, off);
+    };
+    auto eval = [&](const uint32_t (&x)[DEG], const int (&e)[DEG]) {
+        uint32_t out[DEG];
+#pragma unroll
+        for (int k = 0; k < DEG; k++) out[k] = 0;
+#pragma unroll 1
+        for (int s = 0; s < F * BITS; s += BITS) {              // one frame per trip
+)SRC";
+    std::vector<std::string> name((size_t)std::max(prog.n_slots, prog.n_in) + 1);
+    std::vector<int> sm_of((size_t)name.size(), 0);                 // threshold the (sign, magnitude) pair of a slot was emitted for
+    for (int k = 0; k < deg; k++) {
+        o << "            const uint32_t i" << k << " = __builtin_amdgcn_ubfe(x[" << k << "], (uint32_t)s, (uint32_t)BITS);\n";
+        name[(size_t)k] = "i" + std::to_string(k);
+    }
+    o << "            if (chk) {   // parity of the incoming signs: second half of syndrome_check, src/LDPC_Code_LUT.cpp:437-452\n                uint32_t par = 0;\n";
+    for (int k = 0; k < deg; k++) o << "                par ^= i" << k << " < nz ? 1u : 0u;\n";
+    o << "                failw = lshl_or(par, s, failw);\n            }\n";
+    std::vector<std::string> smname(name.size());
+    for (size_t j = 0; j < prog.ops.size(); j++) {
+        const Op &op = prog.ops[j];
+        if (op.kind != 1) { err = "variable-type look-up in a check program"; return false; }
+        if ((size_t)op.dst >= name.size()) { name.resize((size_t)op.dst + 1); sm_of.resize(name.size(), 0); smname.resize(name.size()); }
+        bool all_pow2 = jit_pow2(op.half_len);
+        for (int c = 0; c < op.nchild; c++) all_pow2 = all_pow2 && jit_pow2(op.mult[c]) && jit_pow2((uint32_t)op.childK[c] >> 1);
+        std::string label, par;
+        for (int c = 0; c < op.nchild; c++) {
+            const size_t sl = op.child[c];
+            const std::string &x = name[sl];
+            if (x.empty()) { err = "operand read before it is written"; return false; }
+            const int hh = op.childK[c] >> 1;
+            if (sm_of[sl] != hh || smname[sl] != x) {             // (sign, magnitude) of this value, once
+                o << "            const uint32_t n_" << x << " = " << x << " < " << hh << "u ? 1u : 0u, m_" << x << " = n_" << x << " ? " << hh - 1 << "u - " << x
+                  << " : " << x << " - " << hh << "u;\n";
+                sm_of[sl] = hh; smname[sl] = x;
+            }
+            const std::string m = "m_" + x, n = "n_" + x;
+            if (c == 0) label = op.mult[c] == 1 ? m : "(" + m + " * " + std::to_string(op.mult[c]) + "u)";
+            else if (all_pow2) label = "lshl_or(" + m + ", " + std::to_string(__builtin_ctz(op.mult[c])) + ", " + label + ")";
+            else label = "(" + label + " + " + m + " * " + std::to_string(op.mult[c]) + "u)";
+            par = c == 0 ? n : par + " ^ " + n;
+        }
+        // odd sign parity -> first half of the expanded table, even -> second half (offset half_len)
+        std::string idx = all_pow2 ? "lshl_or((" + par + ") ^ 1u, " + std::to_string(__builtin_ctz(op.half_len)) + ", " + label + ")"
+                                   : "(" + label + " + ((" + par + ") ? 0u : " + std::to_string(op.half_len) + "u))";
+        const std::string t = "t" + std::to_string(j);
+        o << "            const uint32_t " << t << " = tab[" << op.tab_off << "u + " << idx << "];\n";
+        name[(size_t)op.dst] = t;
+        if (op.out_idx >= 0) o << "            out[" << op.out_idx << "] = lshl_or(" << t << ", s, out[" << op.out_idx << "]);\n";
+    }
+    o << "        }\n#pragma unroll\n        for (int k = 0; k < DEG; k++) st_row(base, (uint32_t)e[k] * kRowBytes, lane4, bfi(smask, out[k], x[k]));\n    };\n";
+    if (pipe)
+        o << R"SRC(    uint32_t x[DEG], xn[DEG];
+    int e[DEG], en[DEG];
+    fetch(first, x, e);
+    fetch(first + 1, xn, en);
+    eval(x, e);
+    pipeline_entry_fence();
+    for (int i = first + 1; i < last; i++) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) { x[k] = xn[k]; e[k] = en[k]; }
+        fetch(i + 1, xn, en);
+        eval(x, e);
+    }
+)SRC";
+    else
+        o << R"SRC(    for (int i = first; i < last; i++) {
+        uint32_t x[DEG];
+        int e[DEG];
+        fetch(i, x, e);
+        eval(x, e);
+    }
+)SRC";
+    o << R"SRC(    if (chk) {
+        uint32_t fail[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
+        flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
+    }
+}
+)SRC";
+    src = o.str();
+    return true;
+}
+
 // hiprtc: source -> gfx950 code object (no device needed); log receives the compiler output
 inline bool jit_compile(const std::string &src, std::vector<char> &code, std::string &log)
 {

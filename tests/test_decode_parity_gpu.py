@@ -89,14 +89,16 @@ def test_skewed_pipeline(name, B, snr, env, monkeypatch):
     dec.close()
 
 
-@pytest.mark.parametrize("name", ["c5_minlut", "reg36_n1000_rootonly", "reg36_n1000_high", "reg36_n1000_q5"])
+@pytest.mark.parametrize("name", ["c5_minlut", "reg36_n1000_rootonly", "reg36_n1000_high", "reg36_n1000_q5", "c5_chklut", "reg36_n1000_q3_chklut"])
 def test_generated_kernels_are_used_and_match(name, monkeypatch):
     """jit.hpp: the kernel generated from the node program vs the oracle, and vs the interpreter (LUTLDPC_JIT=0)."""
     cd = oracle_codec(name)
     dec = product_decoder(cd)
     # (degree 3: auto_bin_high over two message leaves IS the balanced shape -> compile-time kernel)
-    jit_expected = name != "reg36_n1000_high"
+    jit_expected = name not in ("reg36_n1000_high", "reg36_n1000_q3_chklut")     # (the latter: balanced variable trees, CHKTREE checks)
     assert dec.describe()["vn_classes"][0]["kernel"] == ("lutldpc_jit_pass" if jit_expected else "vn_balanced_fast_kernel"), dec.describe()
+    if name.endswith("chklut"):
+        assert dec.describe()["cn_classes"][0]["kernel"] == "lutldpc_jit_pass", dec.describe()
     mode = 1 if name.startswith("c5") else 0
     cha, msg, _ = awgn_labels(cd, 700, 4.0 if name.startswith("c5") else 2.2, seed=31, mode=mode)
     _compare(cd, dec, cha, msg, True, True)
@@ -106,6 +108,8 @@ def test_generated_kernels_are_used_and_match(name, monkeypatch):
     monkeypatch.setenv("LUTLDPC_JIT", "0")
     ref = product_decoder(cd)
     assert ref.describe()["vn_classes"][0]["kernel"] == ("tree_pass_kernel<VAR>" if jit_expected else "vn_balanced_fast_kernel")
+    if name.endswith("chklut"):
+        assert ref.describe()["cn_classes"][0]["kernel"] == "tree_pass_kernel<CHK>"
     ref.set_exit_conditions(cd.max_iters, False, False)
     want = ref.lut_decode_batch(cha, msg)
     assert (got[0] == want[0]).all() and (got[1] == want[1]).all()

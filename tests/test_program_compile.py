@@ -89,6 +89,16 @@ def test_jit_source_compiles_without_a_gpu(name):
     dec.close()
 
 
+@pytest.mark.parametrize("name", ["c5_chklut", "reg36_n1000_q3_chklut"])
+def test_jit_check_tree_source_compiles(name):
+    """CHKTREE check update (min_lut = false): sign/magnitude look-ups, one statement per shared look-up."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)
+    src = dec.jit_source(1, 0, 0, compile=True)
+    assert src.count("= tab[") == dec.program_stats(1, 0, 0)["ops"]
+    dec.close()
+
+
 def _has_dec(dec, s):
     try:
         dec.program_stats(2, s, 0)
