@@ -1,0 +1,67 @@
+"""Size-independent properties at BASELINE.json's full configuration (DVB-S2 N=64800, 4-bit labels, all 50
+iterations), where the oracle is too slow to decode a whole batch: four independent kernel paths must agree bit for
+bit, a batch must decode like its parts, frames must not influence each other, and a few frames are checked against
+the oracle at the full iteration count."""
+import numpy as np
+import pytest
+
+from helpers import awgn_labels, oracle_codec, product_decoder
+
+pytestmark = pytest.mark.gpu
+
+PATHS = [{}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"}]
+
+
+def _decode(cd, cha, msg, psc, env, monkeypatch, repeat=1):
+    for k in ("LUTLDPC_SKEW", "LUTLDPC_PACK", "LUTLDPC_USE_FAST", "LUTLDPC_GRAPH", "LUTLDPC_VN_EDGES_PER_WAVE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dec = product_decoder(cd)
+    dec.set_exit_conditions(cd.max_iters, psc, psc)
+    for _ in range(repeat):
+        bits, it = dec.lut_decode_batch(cha, msg)
+    dec.close()
+    return bits, it
+
+
+@pytest.mark.parametrize("name,snr", [("dvbs2_q4", 1.3), ("reg36_n10000_q4", 1.9)])
+def test_kernel_paths_agree_at_full_iteration_count(name, snr, monkeypatch):
+    cd = oracle_codec(name)
+    assert cd.max_iters == 50
+    B = 1100                                                   # three frame groups: uneven halves, ragged last group
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=2026)
+    for psc in (False, True):
+        # fused two-half pipeline replayed as a graph (third call) is the reference point
+        ref_bits, ref_it = _decode(cd, cha, msg, psc, {}, monkeypatch, repeat=3)
+        assert ((ref_it > 0).sum() > 0) and ((np.abs(ref_it) == 50).sum() > 0 or psc)
+        for env in PATHS[1:]:
+            bits, it = _decode(cd, cha, msg, psc, env, monkeypatch)
+            assert (it == ref_it).all(), (env, np.flatnonzero(it != ref_it)[:8])
+            assert (bits == ref_bits).all(), env
+        # the oracle, at the full iteration count, on the first frames
+        cd.set_exit_conditions(50, psc, psc)
+        wb, wi = cd.lut_decode_batch(cha[:3], msg[:3])
+        assert (wi == ref_it[:3]).all() and (wb == ref_bits[:3]).all()
+        # a batch decodes like its parts, and in any frame order
+        b1, i1 = _decode(cd, cha[:600], msg[:600], psc, {}, monkeypatch)
+        b2, i2 = _decode(cd, cha[600:], msg[600:], psc, {}, monkeypatch)
+        assert (np.concatenate([i1, i2]) == ref_it).all() and (np.concatenate([b1, b2]) == ref_bits).all()
+        perm = np.random.default_rng(7).permutation(B)
+        bp, ip = _decode(cd, cha[perm], msg[perm], psc, {}, monkeypatch)
+        assert (ip == ref_it[perm]).all() and (bp == ref_bits[perm]).all()
+
+
+def test_noise_free_and_saturated_frames_at_full_size(monkeypatch):
+    """All labels at the positive extreme: the all-zero codeword is returned, with the iteration codes of the
+    reference (0 when the initial syndrome check is on, 1 with parity_check_iter only, +50 in fixed-work mode)."""
+    cd = oracle_codec("dvbs2_q4")
+    N = cd.code.nvar
+    cha = np.full((520, N), cd.nq_cha - 1, np.uint8)
+    msg = np.full((520, N), cd.nq_msg[0] - 1, np.uint8)
+    dec = product_decoder(cd)
+    for psc, pisc, want in [(True, True, 0), (True, False, 1), (False, False, 50)]:
+        dec.set_exit_conditions(50, psc, pisc)
+        bits, it = dec.lut_decode_batch(cha, msg)
+        assert (it == want).all() and not bits.any()
+    dec.close()
