@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--snr", type=float, default=None, help="Eb/N0 in dB of the synthetic frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not bracket the kernels with HIP events")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--frame-loop-steps", type=int, default=2, help="extra untimed-for-`value` steps of the full sampler+decode+count loop (0 = skip)")
     args = ap.parse_args()
 
@@ -118,11 +119,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or L.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.dist_backend != "nccl":
+        local %= torch.cuda.device_count()        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":           # RCCL over xGMI, one GPU per rank
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     alist, sigma, max_iter, qc, qm, B_default, extra, known_rank = WORKLOADS[args.workload]
     B = args.batch or B_default

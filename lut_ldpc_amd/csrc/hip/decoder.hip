@@ -728,6 +728,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
 int decode_tiles(lutldpc_decoder *d, int B) {
     if (!d->use_graph || d->profiling) return decode_tiles_launch(d, B);
     const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
+    if (d->graphs.size() > 32 && !d->graphs.count(key)) d->drop_graphs();      // callers with ever-changing batch sizes: bound the cache
     auto &slot = d->graphs[key];
     if (slot.exec) {
         HIP_TRY(hipGraphLaunch(slot.exec, d->stream));
