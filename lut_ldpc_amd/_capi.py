@@ -11,6 +11,8 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "liblut_ldpc_amd.so"
+if os.environ.get("LUTLDPC_LIB"):          # A/B runs of two builds of the same library (tools/)
+    LIB_PATH = Path(os.environ["LUTLDPC_LIB"])
 
 OK, ERR_ARG, ERR_PARSE, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = 0, -1, -2, -3, -4, -5
 K_CN_PASS, K_VN_PASS, K_DECISION, K_SYNDROME, K_LAYOUT, K_FRONTEND, K_FUSED_PASS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7

@@ -49,6 +49,7 @@ __device__ __forceinline__ void cn_minsum_body(
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
+    const bool all_active = __ballot(smask != 0xFFFFFFFFu) == 0ull;      // wave-uniform: no frozen frame, plain stores
     const rsrc_t base = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's edge rows
     const uint32_t lane4 = (uint32_t)lane * 4u;
     const int32_t *edges = fast_idx + P.idx_off;
@@ -89,38 +90,56 @@ __device__ __forceinline__ void cn_minsum_body(
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
+            // input sweep: magnitudes, running two smallest, sign parity.  The first two edges need no
+            // comparison against the initial values (after them min1 <= min2 are simply the sorted pair).
             uint32_t min1 = LOW, min2 = LOW, spp = 0;
-            uint32_t pk[DEG];                                     // magnitude | positive flag (bit sbit)
+            uint32_t mg[DEG];
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
                 const uint32_t xh = x[u][k];
                 const uint32_t pos = xh & SB;
                 const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
                 const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
-                spp ^= pos;
-                const uint32_t g1 = ((mag | SB) - min1) & SB;             // mag >= min1
-                const uint32_t k1 = g1 - (g1 >> sbit);
-                const uint32_t lo = bfi(k1, min1, mag);
-                const uint32_t hi = mag ^ min1 ^ lo;
-                const uint32_t g2 = ((min2 | SB) - hi) & SB;              // min2 >= hi
-                const uint32_t k2 = g2 - (g2 >> sbit);
-                min2 = bfi(k2, hi, min2);
-                min1 = lo;
-                pk[k] = mag | pos;
+                spp ^= xh;                                                // sign bits add up in bit sbit (masked below)
+                mg[k] = mag;
+                if (k == 0) {
+                    min1 = mag;
+                } else {
+                    const uint32_t g1 = ((mag | SB) - min1) & SB;         // mag >= min1
+                    const uint32_t k1 = g1 - (g1 >> sbit);
+                    const uint32_t lo = bfi(k1, min1, mag);
+                    const uint32_t hi = mag ^ min1 ^ lo;
+                    if (k == 1) {
+                        min2 = hi;
+                    } else {
+                        const uint32_t g2 = ((min2 | SB) - hi) & SB;      // min2 >= hi
+                        const uint32_t k2 = g2 - (g2 >> sbit);
+                        min2 = bfi(k2, hi, min2);
+                    }
+                    min1 = lo;
+                }
             }
-            const uint32_t tn = spp ^ odd;                                    // parity of the negative inputs (bit sbit)
+            const uint32_t tn = (spp ^ odd) & SB;                             // parity of the negative inputs (bit sbit)
             if (P.check) failw |= tn >> sbit;
+            // output sweep: magnitude = (mag == min1 ? min2 : min1), selected directly in complemented form
+            // (x ^ LOW = nz-1-x), so that the sign step is one op: positive nz+m = ((m^LOW)^LOW)|SB, negative nz-1-m = m^LOW
+            const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;
+            uint32_t r[DEG];
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
-                const uint32_t mag = pk[k] & LOW, pos = pk[k] & SB;
-                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB;   // this edge holds the minimum
+                const uint32_t eq = ~(((mg[k] ^ min1) | SB) - ONE) & SB;      // this edge holds the minimum
                 const uint32_t ke = eq - (eq >> sbit);
-                const uint32_t m = bfi(ke, min2, min1);
-                const uint32_t po = tn ^ pos;                             // extrinsic sign: positive flag
-                const uint32_t nf = po ^ SB;
-                const uint32_t kn = nf - (nf >> sbit);                    // LOW where the result is negative
-                const uint32_t r = (m ^ kn) | po;                         // positive: nz+m ; negative: nz-1-m
-                st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r, x[u][k]));
+                const uint32_t mc = bfi(ke, m2c, m1c);
+                const uint32_t po = (tn ^ x[u][k]) & SB;                      // extrinsic sign: positive flag
+                const uint32_t kp = po - (po >> sbit);                        // LOW where positive
+                r[k] = (mc ^ kp) | po;
+            }
+            if (all_active) {
+#pragma unroll
+                for (int k = 0; k < DEG; k++) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, r[k]);
+            } else {                                                          // frames that already terminated keep their value
+#pragma unroll
+                for (int k = 0; k < DEG; k++) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r[k], x[u][k]));
             }
         }
     };
@@ -301,6 +320,7 @@ __device__ __forceinline__ void vn_balanced_body(
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
+    const bool all_active = __ballot(smask != 0xFFFFFFFFu) == 0ull;      // wave-uniform: no frozen frame, plain stores
     const int32_t *vtab = fast_idx + P.idx_off;                 // dense [n_nodes][2] = {node id, first edge}
     const rsrc_t mbase = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's rows
     const rsrc_t cbase = make_rsrc(cha + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes);
@@ -379,7 +399,7 @@ __device__ __forceinline__ void vn_balanced_body(
             store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         } else {
 #pragma unroll
-            for (int o = 0; o < DV; o++) st_row(mbase, (uint32_t)(e0 + o) * kRowBytes, lane4, bfi(smask, out[o], raw[o]));
+            for (int o = 0; o < DV; o++) st_row(mbase, (uint32_t)(e0 + o) * kRowBytes, lane4, all_active ? out[o] : bfi(smask, out[o], raw[o]));
             if (CHECK && P.write_hard)
                 store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         }
