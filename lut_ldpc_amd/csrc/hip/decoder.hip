@@ -115,9 +115,9 @@ struct lutldpc_decoder {
     int nodes_per_block = 16;
     // specialised kernels: nodes handled by one wave = edges_per_wave / degree (equal work per wave for
     // every degree class); a fixed count when LUTLDPC_NODES_PER_WAVE[_CN] is set.  Measured on MI355X
-    // (DVB-S2, 4096 frames): short waves win -- 4 degree-8 nodes / 8 degree-7 checks per wave.
+    // (DVB-S2, 4096 frames, repeated runs): short waves win -- 2 degree-8 nodes / 4 degree-7 checks per wave.
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
-    int vn_edges_per_wave = 32, cn_edges_per_wave = 56;
+    int vn_edges_per_wave = 16, cn_edges_per_wave = 28;
     int fused_prio = 0;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
@@ -127,7 +127,7 @@ struct lutldpc_decoder {
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
     std::map<std::array<int, 4>, GraphSlot> graphs;       // key {B, psc, pisc, max_iters}
     void drop_graphs() { for (auto &kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); graphs.clear(); }
-    double tail_front = 0.15;   // fused launches: fraction of the item list that the slowest role stays clear of at the end
+    double tail_front = 0.25;   // fused launches: fraction of the item list that the slowest role stays clear of at the end
     // (halving the per-wave work for short codes so that a pass has more waves was measured slower: -13 % on N=500)
     static constexpr int work_shift = 0;
     int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, (vn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
