@@ -760,10 +760,8 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
     int rc = ensure_batch(d, B);
     if (rc) return rc;
     const int Bpad = d->bpad(B), G = Bpad / d->tile();
-    const int N = d->nvar;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
         if ((rc = launch_transpose_in(d, d_cha, d->d_cha_t.p, B, G, d->Nq_Cha))) return rc;
         if ((rc = launch_transpose_in(d, d_msg0, d->d_msg0_t.p, B, G, d->Nq_Msg[0]))) return rc;
         LAUNCH_CHECK();
@@ -1042,7 +1040,6 @@ int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *c
         const int Bpad = d->bpad(B), G = Bpad / d->tile(), N = d->nvar;
         const size_t n = (size_t)B * N;
         HIP_TRY(d->d_out_bits.alloc(n));
-        dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
         if (cha_out) {
             if ((rc = launch_transpose_out(d, d->d_cha_t.p, d->d_out_bits.p, B, G))) return rc;
             LAUNCH_CHECK();
@@ -1071,7 +1068,6 @@ int lutldpc_decoder_sample_labels(lutldpc_decoder *d, const lutldpc_channel_cell
     const int Bpad = d->bpad(B), G = Bpad / d->tile(), N = d->nvar;
     const size_t n = (size_t)B * N;
     HIP_TRY(d->d_in_cha.alloc(n)); HIP_TRY(d->d_in_msg.alloc(n));
-    dim3 grid((unsigned)((N + 31) / 32), (unsigned)G);
     if ((rc = launch_transpose_out(d, d->d_cha_t.p, d->d_in_cha.p, B, G))) return rc;
     if ((rc = launch_transpose_out(d, d->d_msg0_t.p, d->d_in_msg.p, B, G))) return rc;
     HIP_TRY(hipMemcpyAsync(cha, d->d_in_cha.p, n, hipMemcpyDeviceToHost, d->stream));

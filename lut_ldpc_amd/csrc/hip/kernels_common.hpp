@@ -173,7 +173,7 @@ __device__ __forceinline__ void flag_frames(uint32_t *__restrict__ vfail_w, int 
 
 // ---- parameters of the specialised kernels (kernels_fast.hpp and the run-time generated ones of jit.hpp)
 constexpr int kFastMaxTables = 32;     // LUT nodes of one balanced tree (degree <= 33)
-constexpr int kFastTableStride = 256;  // bytes per table slot in LDS (byte tables; nibble tables use the first half)
+constexpr int kFastTableStride = 256;  // bytes per table slot in LDS
 
 struct FastParams {
     int32_t n_nodes, node_off, nodes_per_wave, waves_per_group;

@@ -1,16 +1,17 @@
 // kernels_fast.hpp -- specialised gfx950 kernels for the shapes ber_sim actually produces:
-//   * min-sum check nodes (src/LDPC_Code_LUT.cpp:355-402) with the check's rows held in
-//     registers and byte-parallel (SWAR) arithmetic on the four frames packed in each dword;
+//   * min-sum check nodes (src/LDPC_Code_LUT.cpp:355-402): exact-degree straight-line code, the check's
+//     rows in registers, SWAR arithmetic on the eight nibble frames (or four byte frames) of each dword;
 //   * variable / decision nodes whose tree is the balanced binary tree of
 //     LUT_Tree_Node::gen_bin_balanced_tree (src/LUT_Tree.cpp:200-237) -- the only shape
-//     ber_sim designs in its auto modes (src/LDPC_BER_Sim.cpp:487-489) -- evaluated as
-//     straight-line code with every shared sub-expression computed once.
-// Everything else (file trees, CHKTREE checks, odd alphabets) goes to kernels_generic.hpp.
+//     ber_sim designs in its auto modes (src/LDPC_BER_Sim.cpp:487-489) -- expanded at compile time with
+//     every shared sub-expression computed once and evaluated frame by frame on unpacked labels;
+//   * pass_fused_kernel: the check pass of one half of the frame groups and the variable pass of the
+//     other half in one launch (the skewed two-half pipeline of decoder.hip).
+// Other tree shapes get kernels generated at run time (jit.hpp); kernels_generic.hpp is the fallback.
 //
-// Roofline: both passes are HBM-bound streaming of 256-byte rows (measured ceiling for this
-// in-place gather/scatter pattern on MI355X: ~5.0-5.2 TB/s, tests/microbench/rows.hip).
-// Algorithmic bytes per launch: check pass 2*E*B, variable pass (2*E + N)*B (+N*B when the
-// hard decisions are written for the early-termination test).
+// Roofline: HBM-bound streaming of 256-byte rows.  Algorithmic bytes per launch with b bytes per label:
+// check pass 2*E*b*B, variable pass (2*E + N)*b*B (+N*b*B when the hard decisions are written for the
+// early-termination test); DESIGN.md section 3 has the measured on-chip limits (VALU issue, LDS banks).
 #pragma once
 #include "kernels_common.hpp"
 #include "lut_program.hpp"
@@ -234,10 +235,6 @@ constexpr BalShape<N> make_bal_shape() {
     return S;
 }
 
-template <int N>
-struct Bal {
-    static constexpr BalShape<N> S = make_bal_shape<N>();
-};
 
 // One look-up of ONE frame: label = a | b << sh, table slot `t` in LDS (one v_lshl_or_b32 + one
 // ds_read_u8 with the slot offset as immediate).  The tree of a node is evaluated frame by frame on

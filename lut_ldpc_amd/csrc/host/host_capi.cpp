@@ -155,6 +155,8 @@ int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codewor
     });
 }
 
+}  // extern "C"
+
 namespace {
 ChannelCellTable cells_for(lutldpc_codec *c, double snr_db) {
     const double N0 = std::pow(10.0, -snr_db / 10.0) / c->C->get_rate();
@@ -172,6 +174,8 @@ void make_codewords(lutldpc_codec *c, uint64_t seed, uint32_t stream, uint64_t f
     }
 }
 }  // namespace
+
+extern "C" {
 
 int lutldpc_codec_sim_batch(lutldpc_codec *c, double snr_db, uint64_t seed, uint32_t stream, uint64_t frame0, int B, int zero_codeword, int32_t *stats) {
     return guarded([&] {
