@@ -95,6 +95,10 @@ struct lutldpc_decoder {
     // per node, check classes the DEG edge ids per node (no pointer chasing, scalar loads)
     std::vector<int32_t> fast_idx;
     std::vector<int> vn_idx_off, cn_idx_off;                      // per class
+    // chain fusion (build_fast_index): per check class the offset of its {back, forward} node table (-1 = no links),
+    // per variable class the dense table / count of the nodes NOT updated inside the check pass
+    std::vector<int> chain_idx_off, vn_red_off, vn_red_n;
+    int chain_vclass = -1, n_chain_nodes = 0, use_chain = 1;
     // ---- device
     int device = -1;
     hipStream_t stream = nullptr;
@@ -230,15 +234,70 @@ int build_plan(lutldpc_decoder *d, const std::vector<NodeClass> &cls, const std:
 
 void build_fast_index(lutldpc_decoder *d) {
     d->fast_idx.clear(); d->vn_idx_off.clear(); d->cn_idx_off.clear();
+    d->chain_idx_off.assign(d->cclass.size(), -1); d->vn_red_off.assign(d->vclass.size(), -1); d->vn_red_n.assign(d->vclass.size(), 0);
     for (auto &c : d->vclass) {
         d->vn_idx_off.push_back((int)d->fast_idx.size());
         for (int v : c.nodes) { d->fast_idx.push_back(v); d->fast_idx.push_back(d->vn_ptr[(size_t)v]); }
     }
-    for (auto &c : d->cclass) {
+    // ---- chain links (kernels_fast.hpp: cn_minsum_body<..., CHAIN>).  A degree-2 variable node whose two checks
+    // are neighbours in their degree class AND fall into the same wave (the same run of npw checks) is updated by
+    // that wave inside the check pass: both of its incoming messages are in registers there.  back[c] / fwd[c] =
+    // the node check c shares with its predecessor / successor in the class list (+1, 0 = none).
+    std::vector<int> edge_chk((size_t)d->E, -1), cls_of((size_t)d->nchk, -1), pos_of((size_t)d->nchk, -1);
+    for (int c = 0; c < d->nchk; c++)
+        for (int k = d->cn_ptr[(size_t)c]; k < d->cn_ptr[(size_t)c + 1]; k++) edge_chk[(size_t)d->cn_msg_idx[(size_t)k]] = c;
+    for (size_t ci = 0; ci < d->cclass.size(); ci++)
+        for (size_t j = 0; j < d->cclass[ci].nodes.size(); j++) { cls_of[(size_t)d->cclass[ci].nodes[j]] = (int)ci; pos_of[(size_t)d->cclass[ci].nodes[j]] = (int)j; }
+    std::vector<int> back((size_t)d->nchk, 0), fwd((size_t)d->nchk, 0);
+    std::vector<char> internal((size_t)d->nvar, 0);
+    if (d->use_chain && d->min_lut)
+        for (int v = 0; v < d->nvar; v++) {
+            if (d->dv[(size_t)v] != 2) continue;
+            const int e0 = d->vn_ptr[(size_t)v];
+            int c1 = edge_chk[(size_t)e0], c2 = edge_chk[(size_t)e0 + 1];
+            if (c1 < 0 || c2 < 0 || c1 == c2 || cls_of[(size_t)c1] != cls_of[(size_t)c2]) continue;
+            if (pos_of[(size_t)c1] > pos_of[(size_t)c2]) std::swap(c1, c2);
+            const int deg = d->cclass[(size_t)cls_of[(size_t)c1]].deg, npw = d->npw_cn(deg);
+            if (deg < 2 || deg > kFusedCnDeg[0] || pos_of[(size_t)c2] != pos_of[(size_t)c1] + 1 || pos_of[(size_t)c1] / npw != pos_of[(size_t)c2] / npw) continue;
+            if (fwd[(size_t)c1] || back[(size_t)c2]) continue;
+            fwd[(size_t)c1] = v + 1; back[(size_t)c2] = v + 1; internal[(size_t)v] = 1;
+        }
+    for (size_t ci = 0; ci < d->cclass.size(); ci++) {
+        auto &c = d->cclass[ci];
         d->cn_idx_off.push_back((int)d->fast_idx.size());
-        for (int cn : c.nodes)
-            for (int k = 0; k < c.deg; k++) d->fast_idx.push_back(d->cn_msg_idx[(size_t)(d->cn_ptr[(size_t)cn] + k)]);
+        bool any = false;
+        for (int cn : c.nodes) {
+            std::vector<int> es;
+            for (int k = 0; k < c.deg; k++) es.push_back(d->cn_msg_idx[(size_t)(d->cn_ptr[(size_t)cn] + k)]);
+            // the order of a check's edges is free (min-sum is symmetric): chain edges go to fixed slots, back = 0, forward = 1
+            auto to_slot = [&](int v1, size_t slot) {
+                if (!v1) return;
+                for (size_t k = 0; k < es.size(); k++)
+                    if (es[k] == d->vn_ptr[(size_t)(v1 - 1)] || es[k] == d->vn_ptr[(size_t)(v1 - 1)] + 1) { std::swap(es[k], es[slot]); return; }
+            };
+            to_slot(back[(size_t)cn], 0); to_slot(fwd[(size_t)cn], 1);
+            if (back[(size_t)cn] && fwd[(size_t)cn] && c.deg >= 2) {     // the second swap may have moved the back edge: restore slot 0
+                const int vb = back[(size_t)cn] - 1;
+                if (es[0] != d->vn_ptr[(size_t)vb] && es[0] != d->vn_ptr[(size_t)vb] + 1) to_slot(back[(size_t)cn], 0);
+            }
+            for (int e : es) d->fast_idx.push_back(e);
+            any = any || back[(size_t)cn] || fwd[(size_t)cn];
+        }
+        if (any) {
+            d->chain_idx_off[ci] = (int)d->fast_idx.size();
+            for (int cn : c.nodes) { d->fast_idx.push_back(back[(size_t)cn]); d->fast_idx.push_back(fwd[(size_t)cn]); }
+        }
     }
+    // variable passes that follow a chained check pass skip the nodes it already updated
+    for (size_t vi = 0; vi < d->vclass.size(); vi++) {
+        if (d->vclass[vi].deg != 2) continue;
+        d->vn_red_off[vi] = (int)d->fast_idx.size();
+        for (int v : d->vclass[vi].nodes)
+            if (!internal[(size_t)v]) { d->fast_idx.push_back(v); d->fast_idx.push_back(d->vn_ptr[(size_t)v]); d->vn_red_n[vi]++; }
+        d->chain_vclass = (int)vi;
+    }
+    d->n_chain_nodes = 0;
+    for (char x : internal) d->n_chain_nodes += x;
 }
 
 int compile_all(lutldpc_decoder *d) {
@@ -562,9 +621,22 @@ bool skew_eligible(const lutldpc_decoder *d) {
     return true;
 }
 
-void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int nz, int check) {
+// chain fusion applies to a check pass that is followed by a variable pass (not the last iteration), in fixed-work
+// mode, on the first degree bucket, when the degree-2 class has the compile-time kernel (its root table is staged)
+bool chain_active(const lutldpc_decoder *d, int set) {
+    if (!d->use_chain || d->psc || d->fused_bucket_id != 0 || d->chain_vclass < 0 || d->n_chain_nodes == 0) return false;
+    const FastClassPlan &f = d->var_fast[(size_t)set][(size_t)d->chain_vclass];
+    return f.ok && f.P.n_tables == 1 && f.P.tab_len[0] <= 1024;
+}
+
+void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int nz, int check, int chain_set) {
     for (size_t i = 0; i < d->cclass.size(); i++) {
         RoleParams R{};
+        if (chain_set >= 0 && d->chain_idx_off[i] >= 0) {
+            const FastParams &F2 = d->var_fast[(size_t)chain_set][(size_t)d->chain_vclass].P;
+            R.chain.on = 1; R.chain.idx_off = d->chain_idx_off[i];
+            R.chain.tab_off = F2.tab_off[0]; R.chain.tab_len = F2.tab_len[0]; R.chain.tab_shift = F2.tab_shift[0];
+        }
         const int npw = d->npw_cn(d->cclass[i].deg);
         R.kind = 0; R.deg = d->cclass[i].deg; R.g0 = h.g0; R.G = h.G;
         R.n_nodes = (int)d->cclass[i].nodes.size(); R.nodes_per_wave = npw;
@@ -574,15 +646,16 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
     }
 }
-void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int set, int nz, int check, int write_hard) {
+void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int set, int nz, int check, int write_hard, bool chained) {
     for (size_t i = 0; i < d->vclass.size(); i++) {
         const FastParams &F = d->var_fast[(size_t)set][i].P;
         const int npw = d->npw_vn(F.deg);
         RoleParams R{};
         R.kind = 1; R.deg = F.deg; R.g0 = h.g0; R.G = h.G;
         R.n_nodes = F.n_nodes; R.nodes_per_wave = npw;
-        R.waves_per_group = (R.n_nodes + npw - 1) / npw;
-        R.idx_off = F.idx_off; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard; R.vfail_stride_w = d->Bcap / 4;
+        R.idx_off = F.idx_off;
+        if (chained && (int)i == d->chain_vclass) { R.n_nodes = d->vn_red_n[i]; R.idx_off = d->vn_red_off[i]; }   // the others were updated by the check pass
+        R.waves_per_group = (R.n_nodes + npw - 1) / npw; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard; R.vfail_stride_w = d->Bcap / 4;
         for (int t = 0; t < F.n_tables; t++) { R.tab_off[t] = F.tab_off[t]; R.tab_len[t] = F.tab_len[t]; R.tab_shift[t] = F.tab_shift[t]; }
         FP.role[FP.n_roles++] = R;
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
@@ -657,10 +730,11 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
             const int ii = op / 2;
             if ((op & 1) == 0) {                      // CN(ii)
                 const int check = (psc && ii > 0) ? 1 : 0;
-                add_cn_roles(d, FP, blocks, half[hf], d->Nq_Msg[(size_t)ii] / 2, check);
+                const bool chain = ii != I - 1 && chain_active(d, d->iter_set[(size_t)ii]);
+                add_cn_roles(d, FP, blocks, half[hf], d->Nq_Msg[(size_t)ii] / 2, check, chain ? d->iter_set[(size_t)ii] : -1);
                 if (check) { state_half = hf; state_ii = ii; }
             } else {                                  // VN(ii)
-                add_vn_roles(d, FP, blocks, half[hf], d->iter_set[(size_t)ii], d->Nq_Msg[(size_t)(ii + 1)] / 2, psc, psc);
+                add_vn_roles(d, FP, blocks, half[hf], d->iter_set[(size_t)ii], d->Nq_Msg[(size_t)(ii + 1)] / 2, psc, psc, chain_active(d, d->iter_set[(size_t)ii]));
             }
         }
         if ((rc = launch_fused_pass(d, FP, blocks, psc != 0))) return rc;
@@ -830,7 +904,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 
@@ -911,6 +985,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }

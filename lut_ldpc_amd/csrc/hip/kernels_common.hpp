@@ -191,6 +191,12 @@ struct FastParams {
     int32_t nib;                        // (unused: nibble-packed LDS tables were measured slower and removed)
     int32_t vfail_stride_w;             // words between two copies of the early-termination flags (see flag_frames)
 };
+// chain fusion of the check pass (cn_minsum_body<..., CHAIN>): which table, which links
+struct ChainParams {
+    int32_t on;            // 1: update the linked degree-2 variable nodes inside this check pass
+    int32_t idx_off;       // dense [n_nodes][2] = {back node + 1, forward node + 1} (0 = none)
+    int32_t tab_off, tab_len, tab_shift;    // the degree-2 class' root table: label = message | channel << tab_shift
+};
 
 // (x << s) | y in one instruction, s wave-uniform
 __device__ __forceinline__ uint32_t lshl_or(uint32_t x, int s, uint32_t y) {

@@ -36,11 +36,22 @@ namespace lutldpc {
 // DEG is the exact check degree (straight-line code, all row loads of UNR checks issued up front);
 // `edges` is the dense [n_nodes][DEG] table of edge ids of this degree class, read with scalar loads.
 // `block` = index of the 4-wave block within this degree class; PT = FastParams or RoleParams.
-template <int DEG, int UNR, int PACK, typename PT>
+// CHAIN (UNR = 1): a degree-2 variable node shared by two consecutive checks of this wave is updated here -- its two
+// incoming messages are this check's output r[0] and the previous check's output r[1], held back in `pend` -- and
+// the NEW variable-to-check messages are stored instead of the check-to-variable ones: one write and one read less per
+// such edge and iteration (decoder.hip: build_fast_index puts the chain edges at slots 0 / 1 of the edge table).
+template <int DEG, int UNR, int PACK, bool CHAIN, typename PT>
 __device__ __forceinline__ void cn_minsum_body(
-    const PT &P, int block, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
-    const int32_t *__restrict__ fast_idx)
+    const PT &P, int block, uint8_t *msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+    const int32_t *__restrict__ fast_idx, const ChainParams CH = ChainParams{}, uint8_t *lds_tab = nullptr,
+    const uint8_t *cha = nullptr, const uint8_t *__restrict__ tables = nullptr)
 {
+    static_assert(!CHAIN || (UNR == 1 && DEG >= 2), "chain fusion: one check per step");
+    if constexpr (CHAIN) {      // the degree-2 root table (block-uniform call)
+        const int i = threadIdx.x;
+        if (i < CH.tab_len / 4) reinterpret_cast<uint32_t *>(lds_tab)[i] = reinterpret_cast<const uint32_t *>(tables + CH.tab_off)[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));    // wave-uniform -> SGPR
     const int gl = wave / P.waves_per_group;
@@ -73,18 +84,27 @@ __device__ __forceinline__ void cn_minsum_body(
     // compiler wait with the exact vmcnt (loads done, the stores behind them still in flight).  A fetch
     // past the end of the chunk uses an out-of-range lane offset: the buffer unit returns 0 without
     // touching memory.
+    // chain state: links of the check being evaluated / fetched, the held-back output of the previous check
+    const int32_t *links = CHAIN ? fast_idx + CH.idx_off : nullptr;
+    const rsrc_t cbase = CHAIN ? make_rsrc(cha + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes) : base;
+    int lb = 0, lf = 0, lbn = 0, lfn = 0;          // back / forward node + 1 of the current and of the next check
+    uint32_t xc = 0, xcn = 0;                      // channel row of the back node
+    uint32_t pend = 0, pend_old = 0;
+    int pend_e = 0;
     auto fetch = [&](int i, uint32_t (&xx)[UNR][DEG], int (&ee)[UNR][DEG]) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int ii = (i + u < last) ? i + u : last - 1;
 #pragma unroll
             for (int k = 0; k < DEG; k++) ee[u][k] = edges[(size_t)ii * DEG + k];
+            if constexpr (CHAIN) { lbn = links[2 * (size_t)ii]; lfn = links[2 * (size_t)ii + 1]; }
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const uint32_t off = lane4 | ((i + u < last) ? 0u : 0x80000000u);
 #pragma unroll
             for (int k = 0; k < DEG; k++) xx[u][k] = ld_row(base, (uint32_t)ee[u][k] * kRowBytes, off);
+            if constexpr (CHAIN) xcn = ld_row(cbase, (uint32_t)(lbn > 0 ? lbn - 1 : 0) * kRowBytes, (i + u < last && lbn > 0) ? lane4 : (lane4 | 0x80000000u));
         }
     };
     auto eval = [&](int i, const uint32_t (&x)[UNR][DEG], const int (&e)[UNR][DEG]) {
@@ -135,7 +155,30 @@ __device__ __forceinline__ void cn_minsum_body(
                 const uint32_t kp = po - (po >> sbit);                        // LOW where positive
                 r[k] = (mc ^ kp) | po;
             }
-            if (all_active) {
+            if constexpr (CHAIN) {
+                constexpr int F = 4 * PACK, BITS = 8 / PACK;
+                if (lb) {       // wave-uniform: the node shared with the previous check
+                    uint32_t o_prev = 0, o_this = 0;
+#pragma unroll 1
+                    for (int s = 0; s < F * BITS; s += 2 * BITS) {
+#pragma unroll
+                        for (int t = 0; t < 2; t++) {
+                            const int sb = s + t * BITS;
+                            const uint32_t a = __builtin_amdgcn_ubfe(pend, (uint32_t)sb, (uint32_t)BITS), b = __builtin_amdgcn_ubfe(r[0], (uint32_t)sb, (uint32_t)BITS);
+                            const uint32_t c = __builtin_amdgcn_ubfe(xc, (uint32_t)sb, (uint32_t)BITS);
+                            // src/LUT_Tree.cpp:774-790 for two inputs: the message to one check is ROOT(message from the other, channel)
+                            o_prev = lshl_or(lds_tab[lshl_or(c, CH.tab_shift, b)], sb, o_prev);
+                            o_this = lshl_or(lds_tab[lshl_or(c, CH.tab_shift, a)], sb, o_this);
+                        }
+                    }
+                    st_row(base, (uint32_t)pend_e * kRowBytes, lane4, bfi(smask, o_prev, pend_old));
+                    r[0] = o_this;
+                }
+                if (lf) { pend = r[1]; pend_e = e[u][1]; pend_old = x[u][1]; }
+#pragma unroll
+                for (int k = 0; k < DEG; k++)
+                    if (!(k == 1 && lf)) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r[k], x[u][k]));
+            } else if (all_active) {
 #pragma unroll
                 for (int k = 0; k < DEG; k++) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, r[k]);
             } else {                                                          // frames that already terminated keep their value
@@ -148,6 +191,7 @@ __device__ __forceinline__ void cn_minsum_body(
         uint32_t x[UNR][DEG], xn[UNR][DEG];
         int e[UNR][DEG], en[UNR][DEG];
         fetch(first, x, e);
+        if constexpr (CHAIN) { lb = lbn; lf = lfn; xc = xcn; }
         fetch(first + UNR, xn, en);
         eval(first, x, e);
         pipeline_entry_fence();
@@ -156,6 +200,7 @@ __device__ __forceinline__ void cn_minsum_body(
             for (int u = 0; u < UNR; u++)
 #pragma unroll
                 for (int k = 0; k < DEG; k++) { x[u][k] = xn[u][k]; e[u][k] = en[u][k]; }
+            if constexpr (CHAIN) { lb = lbn; lf = lfn; xc = xcn; }
             fetch(i + UNR, xn, en);
             eval(i, x, e);
         }
@@ -166,6 +211,7 @@ __device__ __forceinline__ void cn_minsum_body(
             uint32_t x[UNR][DEG];
             int e[UNR][DEG];
             fetch(i, x, e);
+            if constexpr (CHAIN) { lb = lbn; lf = lfn; xc = xcn; }
             eval(i, x, e);
         }
     }
@@ -182,7 +228,7 @@ __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
     FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx)
 {
-    cn_minsum_body<DEG, UNR, PACK>(P, (int)blockIdx.x, msgs, state_w, vfail_w, fast_idx);
+    cn_minsum_body<DEG, UNR, PACK, false>(P, (int)blockIdx.x, msgs, state_w, vfail_w, fast_idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -463,6 +509,7 @@ struct RoleParams {
     int32_t n_nodes, nodes_per_wave, waves_per_group, idx_off;
     int32_t E, N, nz, shift_msg, check, write_hard;
     int32_t vfail_stride_w;
+    ChainParams chain;     // check roles only
     int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
 };
 struct FusedParams {
@@ -471,10 +518,10 @@ struct FusedParams {
     RoleParams role[kFusedMaxRoles];
 };
 
-template <int PACK, int... Ds>
+template <int PACK, bool CHAIN, int... Ds>
 __device__ __forceinline__ void fused_cn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *msgs, const uint32_t *state_w,
-                                                uint32_t *vfail_w, const int32_t *fast_idx) {
-    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK>(P, block, msgs, state_w, vfail_w, fast_idx), 0) : 0), ...);
+                                                uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables) {
+    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables), 0) : 0), ...);
 }
 template <int PACK, bool CHECK, int... Ds>
 __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *lds_tab, uint8_t *msgs,
@@ -501,7 +548,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0
     if (FP.prio && P.kind) {                       // LUT-heavy waves first: they are the long ones
         if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     }
-    if (P.kind == 0) fused_cn_switch<PACK>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx);
+    if (P.kind == 0) {
+        // chain fusion exists in the small-degree bucket only (dual-diagonal codes: DVB-S2, IRA) and not with early termination
+        if (BUCKET == 0 && !CHECK && P.chain.on) fused_cn_switch<PACK, BUCKET == 0 && !CHECK>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables);
+        else fused_cn_switch<PACK, false>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables);
+    }
     else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
 

@@ -116,6 +116,19 @@ def test_generated_kernels_are_used_and_match(name, monkeypatch):
     ref.close()
 
 
+def test_chain_fusion_is_on_for_the_dual_diagonal_code():
+    """DVB-S2: 3 of 4 parity nodes (degree 2, checks c and c+1) are updated inside the check pass in fixed-work mode."""
+    cd = oracle_codec("dvbs2_q4_i6")
+    dec = product_decoder(cd)
+    assert dec.describe()["chain_nodes"] == 24299, dec.describe()
+    cha, msg, _ = awgn_labels(cd, 1030, 1.0, seed=99)          # three frame groups: halves of two and one
+    _compare(cd, dec, cha, msg, False, False)
+    dec.set_exit_conditions(cd.max_iters, True, False)         # early termination: chain fusion off, same buffers ...
+    dec.lut_decode_batch(cha[:600], msg[:600])
+    _compare(cd, dec, cha[:520], msg[:520], False, False)      # ... and on again
+    dec.close()
+
+
 def test_graph_replay_of_repeated_decodes():
     """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
     and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size

@@ -9,11 +9,12 @@ from helpers import awgn_labels, oracle_codec, product_decoder
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [{}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"}]
+PATHS = [{}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"},
+         {"LUTLDPC_CHAIN": "0"}, {"LUTLDPC_CN_EDGES_PER_WAVE": "56", "LUTLDPC_PACK": "1"}]
 
 
 def _decode(cd, cha, msg, psc, env, monkeypatch, repeat=1):
-    for k in ("LUTLDPC_SKEW", "LUTLDPC_PACK", "LUTLDPC_USE_FAST", "LUTLDPC_GRAPH", "LUTLDPC_VN_EDGES_PER_WAVE"):
+    for k in ("LUTLDPC_SKEW", "LUTLDPC_PACK", "LUTLDPC_USE_FAST", "LUTLDPC_GRAPH", "LUTLDPC_VN_EDGES_PER_WAVE", "LUTLDPC_CHAIN", "LUTLDPC_CN_EDGES_PER_WAVE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -32,7 +33,8 @@ def test_kernel_paths_agree_at_full_iteration_count(name, snr, monkeypatch):
     B = 1100                                                   # three frame groups: uneven halves, ragged last group
     cha, msg, _ = awgn_labels(cd, B, snr, seed=2026)
     for psc in (False, True):
-        # fused two-half pipeline replayed as a graph (third call) is the reference point
+        # fused two-half pipeline replayed as a graph (third call) is the reference point; on DVB-S2 it runs with chain
+        # fusion (degree-2 parity nodes updated inside the check pass), which PATHS switches off / re-partitions
         ref_bits, ref_it = _decode(cd, cha, msg, psc, {}, monkeypatch, repeat=3)
         assert ((ref_it > 0).sum() > 0) and ((np.abs(ref_it) == 50).sum() > 0 or psc)
         for env in PATHS[1:]:
