@@ -119,9 +119,9 @@ struct lutldpc_decoder {
     int nodes_per_block = 16;
     // specialised kernels: nodes handled by one wave = edges_per_wave / degree (equal work per wave for
     // every degree class); a fixed count when LUTLDPC_NODES_PER_WAVE[_CN] is set.  Measured on MI355X
-    // (DVB-S2, 4096 frames, repeated runs): short waves win -- 2 degree-8 nodes / 4 degree-7 checks per wave.
+    // (DVB-S2, 4096 frames, repeated runs): short waves win -- 2 degree-8 nodes / 6 degree-7 checks per wave (longer check runs also keep more chain nodes inside a wave).
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
-    int vn_edges_per_wave = 16, cn_edges_per_wave = 28;
+    int vn_edges_per_wave = 16, cn_edges_per_wave = 42;
     int fused_prio = 0;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
