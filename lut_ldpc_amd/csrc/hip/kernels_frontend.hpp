@@ -49,10 +49,18 @@ struct Philox {
     }
 };
 
-__device__ __forceinline__ int cell_of(const ChannelCells &C, uint64_t u) {
-    int j = 0;
-    for (int k = 0; k < C.n_cells - 1; k++) j += (u >= C.thr[k]) ? 1 : 0;
-    return j;
+// cell index = number of thresholds <= u.  The thresholds ascend (checked on the host), so this is an upper-bound
+// binary search: 7 steps over the LDS copy of the table instead of up to 71 64-bit compares per sample.
+__device__ __forceinline__ int cell_of(const uint64_t *thr_lds, int n_thr, uint64_t u) {
+    int lo = 0, n = n_thr;                    // invariant: thr[0..lo) <= u, answer in [lo, lo + n]
+#pragma unroll
+    for (int step = 0; step < 7; step++) {    // 2^7 > kMaxCells
+        const int half = n >> 1;
+        const bool right = n > 0 && u >= thr_lds[lo + half];
+        lo = right ? lo + half + 1 : lo;
+        n = right ? n - half - 1 : half;
+    }
+    return lo;
 }
 
 // Writes cha_t / msg0_t rows (row layout) for B frames starting at global frame index frame0 and
@@ -64,6 +72,10 @@ __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint
                                                             uint8_t *__restrict__ msg_t, int32_t *__restrict__ stats, int pairs_per_thread)
 {
     constexpr int F = 4 * PACK;                                     // frames per lane
+    __shared__ uint64_t thr_lds[kMaxCells];
+    if (threadIdx.x < kMaxCells) thr_lds[threadIdx.x] = C.thr[threadIdx.x < C.n_cells - 1 ? threadIdx.x : 0];
+    __syncthreads();
+    const int n_thr = C.n_cells - 1;
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int npairs = (N + 1) / 2;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint
             for (int hh = 0; hh < 2; hh++) {
                 const int v = 2 * p + hh;
                 if (v >= N) continue;
-                const int cell = cell_of(C, u[hh]);
+                const int cell = cell_of(thr_lds, n_thr, u[hh]);
                 const int bit = codewords ? codewords[(size_t)fl * N + v] : 0;
                 const uint32_t a = bit ? C.cha_m[cell] : C.cha[cell], m = bit ? C.msg_m[cell] : C.msg[cell];
                 const int sl = bit ? (C.neg[cell] ^ 1) : C.neg[cell];     // slicer decision
