@@ -440,7 +440,7 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_hard.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_state.alloc((size_t)Bpad));
-    HIP_TRY(d->d_vfail.alloc((size_t)Bpad * kVfailSlots));      // kVfailSlots copies, Bcap bytes apart (flag_frames)
+    HIP_TRY(d->d_vfail.alloc((size_t)Bpad * kVfailSlots * 2));  // two buffers (skewed pipeline: this / next exit test) of kVfailSlots copies, Bcap bytes apart
     HIP_TRY(d->d_iters.alloc((size_t)Bpad));
     d->Bcap = Bpad;
     return LUTLDPC_OK;
@@ -460,22 +460,24 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     } while (0)
 
 // frames f0 .. f1-1 (both multiples of 256); default: the whole padded batch
-int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value, int f0 = 0, int f1 = -1) {
+// `sel`: which of the two flag buffers the exit test reads and clears (always 0 outside the skewed pipeline)
+int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value, int f0 = 0, int f1 = -1, int sel = 0) {
     Timed t(d, LUTLDPC_K_LAYOUT);
     if (f1 < 0) f1 = Bpad;
     if (f1 <= f0) return LUTLDPC_OK;
+    if (mode == 0) HIP_TRY(hipMemsetAsync(d->d_vfail.p + (size_t)kVfailSlots * d->Bcap, 0, (size_t)kVfailSlots * d->Bcap, d->stream));
     hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)((f1 - f0) / 256)), dim3(256), 0, d->stream,
-                       d->d_state.p, d->d_vfail.p, d->d_iters.p, B, f0, f1, mode, value, d->Bcap);
+                       d->d_state.p, d->d_vfail.p + (size_t)sel * kVfailSlots * d->Bcap, d->d_iters.p, B, f0, f1, mode, value, d->Bcap);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
 
-int launch_syndrome(lutldpc_decoder *d, int G) {
+int launch_syndrome(lutldpc_decoder *d, int G, int sel = 0) {
     Timed t(d, LUTLDPC_K_SYNDROME);
     const int cpw = 8;
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
     PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
-                       reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
+                       reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p + (size_t)sel * kVfailSlots * d->Bcap),
                        d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw, d->Bcap / 4));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -621,21 +623,33 @@ bool skew_eligible(const lutldpc_decoder *d) {
     return true;
 }
 
-// chain fusion applies to a check pass that is followed by a variable pass (not the last iteration), in fixed-work
-// mode, on the first degree bucket, when the degree-2 class has the compile-time kernel (its root table is staged)
+// chain fusion applies to a check pass that is followed by a variable pass (not the last iteration), on the first
+// degree bucket, when the degree-2 class has the compile-time kernel (its root table is staged)
 bool chain_active(const lutldpc_decoder *d, int set) {
-    if (!d->use_chain || d->psc || d->fused_bucket_id != 0 || d->chain_vclass < 0 || d->n_chain_nodes == 0) return false;
+    if (!d->use_chain || d->fused_bucket_id != 0 || d->chain_vclass < 0 || d->n_chain_nodes == 0) return false;
     const FastClassPlan &f = d->var_fast[(size_t)set][(size_t)d->chain_vclass];
     return f.ok && f.P.n_tables == 1 && f.P.tab_len[0] <= 1024;
 }
 
-void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int nz, int check, int chain_set) {
+void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int ii, int check) {
+    const int I = d->max_iters, nz = d->Nq_Msg[(size_t)ii] / 2;
+    const int buf_w = kVfailSlots * d->Bcap / 4;                      // words per flag buffer
+    const bool on = ii != I - 1 && chain_active(d, d->iter_set[(size_t)ii]);
+    const bool hard = d->psc && ii >= 1 && chain_active(d, d->iter_set[(size_t)(ii - 1)]);
     for (size_t i = 0; i < d->cclass.size(); i++) {
         RoleParams R{};
-        if (chain_set >= 0 && d->chain_idx_off[i] >= 0) {
-            const FastParams &F2 = d->var_fast[(size_t)chain_set][(size_t)d->chain_vclass].P;
-            R.chain.on = 1; R.chain.idx_off = d->chain_idx_off[i];
-            R.chain.tab_off = F2.tab_off[0]; R.chain.tab_len = F2.tab_len[0]; R.chain.tab_shift = F2.tab_shift[0];
+        R.vfail_off_w = (ii & 1) * buf_w;                             // parity flags: this iteration's exit test
+        if ((on || hard) && d->chain_idx_off[i] >= 0) {
+            R.chain.idx_off = d->chain_idx_off[i];
+            R.chain.hard = hard ? 1 : 0;
+            if (on) {
+                const FastParams &F2 = d->var_fast[(size_t)d->iter_set[(size_t)ii]][(size_t)d->chain_vclass].P;
+                R.chain.on = 1;
+                R.chain.tab_off = F2.tab_off[0]; R.chain.tab_len = F2.tab_len[0]; R.chain.tab_shift = F2.tab_shift[0];
+                R.chain.check = d->psc ? 1 : 0;
+                R.chain.vfail_off_w = ((ii + 1) & 1) * buf_w;         // unanimity of the nodes updated here: the next exit test
+                R.chain.sbit_out = __builtin_ctz((unsigned)(d->Nq_Msg[(size_t)(ii + 1)] / 2) | 0x100u);
+            }
         }
         const int npw = d->npw_cn(d->cclass[i].deg);
         R.kind = 0; R.deg = d->cclass[i].deg; R.g0 = h.g0; R.G = h.G;
@@ -646,7 +660,10 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
     }
 }
-void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int set, int nz, int check, int write_hard, bool chained) {
+void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &blocks, HalfRange h, int ii, int check, int write_hard) {
+    const int set = d->iter_set[(size_t)ii], nz = d->Nq_Msg[(size_t)(ii + 1)] / 2;
+    const bool chained = chain_active(d, set);
+    const int buf_w = kVfailSlots * d->Bcap / 4;
     for (size_t i = 0; i < d->vclass.size(); i++) {
         const FastParams &F = d->var_fast[(size_t)set][i].P;
         const int npw = d->npw_vn(F.deg);
@@ -656,6 +673,7 @@ void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         R.idx_off = F.idx_off;
         if (chained && (int)i == d->chain_vclass) { R.n_nodes = d->vn_red_n[i]; R.idx_off = d->vn_red_off[i]; }   // the others were updated by the check pass
         R.waves_per_group = (R.n_nodes + npw - 1) / npw; R.E = d->E; R.N = d->nvar; R.nz = nz; R.shift_msg = F.shift_msg; R.check = check; R.write_hard = write_hard; R.vfail_stride_w = d->Bcap / 4;
+        R.vfail_off_w = ((ii + 1) & 1) * buf_w;                       // unanimity flags: the exit test after the NEXT check pass
         for (int t = 0; t < F.n_tables; t++) { R.tab_off[t] = F.tab_off[t]; R.tab_len[t] = F.tab_len[t]; R.tab_shift[t] = F.tab_shift[t]; }
         FP.role[FP.n_roles++] = R;
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
@@ -730,17 +748,16 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
             const int ii = op / 2;
             if ((op & 1) == 0) {                      // CN(ii)
                 const int check = (psc && ii > 0) ? 1 : 0;
-                const bool chain = ii != I - 1 && chain_active(d, d->iter_set[(size_t)ii]);
-                add_cn_roles(d, FP, blocks, half[hf], d->Nq_Msg[(size_t)ii] / 2, check, chain ? d->iter_set[(size_t)ii] : -1);
+                add_cn_roles(d, FP, blocks, half[hf], ii, check);
                 if (check) { state_half = hf; state_ii = ii; }
             } else {                                  // VN(ii)
-                add_vn_roles(d, FP, blocks, half[hf], d->iter_set[(size_t)ii], d->Nq_Msg[(size_t)(ii + 1)] / 2, psc, psc, chain_active(d, d->iter_set[(size_t)ii]));
+                add_vn_roles(d, FP, blocks, half[hf], ii, psc, psc);
             }
         }
         if ((rc = launch_fused_pass(d, FP, blocks, psc != 0))) return rc;
         if (state_half >= 0) {                        // :327-329 returns (ii-1)+1
             const int f0 = half[state_half].g0 * d->tile(), f1 = f0 + half[state_half].G * d->tile();
-            if ((rc = launch_state(d, B, Bpad, 2, state_ii, f0, f1))) return rc;
+            if ((rc = launch_state(d, B, Bpad, 2, state_ii, f0, f1, state_ii & 1))) return rc;
         }
     }
     return LUTLDPC_OK;
@@ -789,8 +806,9 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     }
     // :340-349
     if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], d->dec_jit.empty() ? nullptr : &d->dec_jit[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
-    if ((rc = launch_syndrome(d, G))) return rc;
-    if ((rc = launch_state(d, B, Bpad, 3, I))) return rc;
+    const int fsel = skewed ? (I & 1) : 0;            // the flag buffer no pass of the skewed pipeline has written since its last test
+    if ((rc = launch_syndrome(d, G, fsel))) return rc;
+    if ((rc = launch_state(d, B, Bpad, 3, I, 0, -1, fsel))) return rc;
     if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
     return LUTLDPC_OK;
 }

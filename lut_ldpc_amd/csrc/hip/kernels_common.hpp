@@ -190,12 +190,17 @@ struct FastParams {
     int32_t tab_shift[kFastMaxTables];  // log2 alphabet of each table's first child
     int32_t nib;                        // (unused: nibble-packed LDS tables were measured slower and removed)
     int32_t vfail_stride_w;             // words between two copies of the early-termination flags (see flag_frames)
+    int32_t vfail_off_w;                // word offset of the flag buffer this pass reports to (skewed pipeline: two buffers)
 };
 // chain fusion of the check pass (cn_minsum_body<..., CHAIN>): which table, which links
 struct ChainParams {
     int32_t on;            // 1: update the linked degree-2 variable nodes inside this check pass
     int32_t idx_off;       // dense [n_nodes][2] = {back node + 1, forward node + 1} (0 = none)
     int32_t tab_off, tab_len, tab_shift;    // the degree-2 class' root table: label = message | channel << tab_shift
+    // early termination (parity_check_iter): the unanimity test of the nodes updated here belongs to the NEXT exit test
+    // (other flag buffer); their decided bits -- the signs of the messages they sent LAST iteration -- are stored by the
+    // check pass that reads those messages (hard = 1), because the variable pass skipped them
+    int32_t check, hard, vfail_off_w, sbit_out;
 };
 
 // (x << s) | y in one instruction, s wave-uniform

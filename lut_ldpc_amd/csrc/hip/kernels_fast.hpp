@@ -44,12 +44,12 @@ template <int DEG, int UNR, int PACK, bool CHAIN, typename PT>
 __device__ __forceinline__ void cn_minsum_body(
     const PT &P, int block, uint8_t *msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx, const ChainParams CH = ChainParams{}, uint8_t *lds_tab = nullptr,
-    const uint8_t *cha = nullptr, const uint8_t *__restrict__ tables = nullptr)
+    const uint8_t *cha = nullptr, const uint8_t *__restrict__ tables = nullptr, uint8_t *hard = nullptr)
 {
     static_assert(!CHAIN || (UNR == 1 && DEG >= 2), "chain fusion: one check per step");
     if constexpr (CHAIN) {      // the degree-2 root table (block-uniform call)
         const int i = threadIdx.x;
-        if (i < CH.tab_len / 4) reinterpret_cast<uint32_t *>(lds_tab)[i] = reinterpret_cast<const uint32_t *>(tables + CH.tab_off)[i];
+        if (CH.on && i < CH.tab_len / 4) reinterpret_cast<uint32_t *>(lds_tab)[i] = reinterpret_cast<const uint32_t *>(tables + CH.tab_off)[i];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void cn_minsum_body(
     const rsrc_t cbase = CHAIN ? make_rsrc(cha + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes) : base;
     int lb = 0, lf = 0, lbn = 0, lfn = 0;          // back / forward node + 1 of the current and of the next check
     uint32_t xc = 0, xcn = 0;                      // channel row of the back node
-    uint32_t pend = 0, pend_old = 0;
+    uint32_t pend = 0, pend_old = 0, chainfail = 0;
     int pend_e = 0;
     auto fetch = [&](int i, uint32_t (&xx)[UNR][DEG], int (&ee)[UNR][DEG]) {
 #pragma unroll
@@ -104,7 +104,7 @@ __device__ __forceinline__ void cn_minsum_body(
             const uint32_t off = lane4 | ((i + u < last) ? 0u : 0x80000000u);
 #pragma unroll
             for (int k = 0; k < DEG; k++) xx[u][k] = ld_row(base, (uint32_t)ee[u][k] * kRowBytes, off);
-            if constexpr (CHAIN) xcn = ld_row(cbase, (uint32_t)(lbn > 0 ? lbn - 1 : 0) * kRowBytes, (i + u < last && lbn > 0) ? lane4 : (lane4 | 0x80000000u));
+            if constexpr (CHAIN) xcn = ld_row(cbase, (uint32_t)(lbn > 0 ? lbn - 1 : 0) * kRowBytes, (i + u < last && lbn > 0 && CH.on) ? lane4 : (lane4 | 0x80000000u));
         }
     };
     auto eval = [&](int i, const uint32_t (&x)[UNR][DEG], const int (&e)[UNR][DEG]) {
@@ -157,8 +157,14 @@ __device__ __forceinline__ void cn_minsum_body(
             }
             if constexpr (CHAIN) {
                 constexpr int F = 4 * PACK, BITS = 8 / PACK;
-                if (lb) {       // wave-uniform: the node shared with the previous check
-                    uint32_t o_prev = 0, o_this = 0;
+                if (lb && CH.hard) {
+                    // decided bit of the node shared with the previous check = sign of the message it sent to this check last
+                    // iteration (unanimous whenever the frame passes the exit test, src/LDPC_Code_LUT.cpp:437-452)
+                    const uint32_t neg = (~x[u][0] >> sbit) & ONE;
+                    store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + ((size_t)g * (size_t)P.N + (size_t)(lb - 1)) * kRowBytes + lane4), neg, smask);
+                }
+                if (lb && CH.on) {       // wave-uniform: the node shared with the previous check
+                    uint32_t o_prev = 0, o_this = 0, dif = 0;
 #pragma unroll 1
                     for (int s = 0; s < F * BITS; s += 2 * BITS) {
 #pragma unroll
@@ -167,17 +173,20 @@ __device__ __forceinline__ void cn_minsum_body(
                             const uint32_t a = __builtin_amdgcn_ubfe(pend, (uint32_t)sb, (uint32_t)BITS), b = __builtin_amdgcn_ubfe(r[0], (uint32_t)sb, (uint32_t)BITS);
                             const uint32_t c = __builtin_amdgcn_ubfe(xc, (uint32_t)sb, (uint32_t)BITS);
                             // src/LUT_Tree.cpp:774-790 for two inputs: the message to one check is ROOT(message from the other, channel)
-                            o_prev = lshl_or(lds_tab[lshl_or(c, CH.tab_shift, b)], sb, o_prev);
-                            o_this = lshl_or(lds_tab[lshl_or(c, CH.tab_shift, a)], sb, o_this);
+                            const uint32_t vp = lds_tab[lshl_or(c, CH.tab_shift, b)], vt = lds_tab[lshl_or(c, CH.tab_shift, a)];
+                            o_prev = lshl_or(vp, sb, o_prev);
+                            o_this = lshl_or(vt, sb, o_this);
+                            if (CH.check) dif = lshl_or(((vp ^ vt) >> CH.sbit_out) & 1u, sb, dif);    // the two outgoing signs differ
                         }
                     }
+                    chainfail |= dif;
                     st_row(base, (uint32_t)pend_e * kRowBytes, lane4, bfi(smask, o_prev, pend_old));
                     r[0] = o_this;
                 }
-                if (lf) { pend = r[1]; pend_e = e[u][1]; pend_old = x[u][1]; }
+                if (lf && CH.on) { pend = r[1]; pend_e = e[u][1]; pend_old = x[u][1]; }
 #pragma unroll
                 for (int k = 0; k < DEG; k++)
-                    if (!(k == 1 && lf)) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r[k], x[u][k]));
+                    if (!(k == 1 && lf && CH.on)) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, bfi(smask, r[k], x[u][k]));
             } else if (all_active) {
 #pragma unroll
                 for (int k = 0; k < DEG; k++) st_row(base, (uint32_t)e[u][k] * kRowBytes, lane4, r[k]);
@@ -219,7 +228,15 @@ __device__ __forceinline__ void cn_minsum_body(
         uint32_t fail[PACK];
 #pragma unroll
         for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
-        flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
+        flag_frames<PACK>(vfail_w + P.vfail_off_w, P.vfail_stride_w, g, lane, fail, amask);
+    }
+    if constexpr (CHAIN) {
+        if (CH.check && CH.on) {        // unanimity of the nodes updated here: part of the next exit test
+            uint32_t fail[PACK];
+#pragma unroll
+            for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(chainfail, h);
+            flag_frames<PACK>(vfail_w + CH.vfail_off_w, P.vfail_stride_w, g, lane, fail, amask);
+        }
     }
 }
 
@@ -464,7 +481,7 @@ __device__ __forceinline__ void vn_balanced_body(
         uint32_t fail[PACK];
 #pragma unroll
         for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(failw, h);
-        flag_frames<PACK>(vfail_w, P.vfail_stride_w, g, lane, fail, amask);
+        flag_frames<PACK>(vfail_w + P.vfail_off_w, P.vfail_stride_w, g, lane, fail, amask);
     }
 }
 
@@ -508,7 +525,7 @@ struct RoleParams {
     int32_t g0, G;         // frame groups g0 .. g0+G-1
     int32_t n_nodes, nodes_per_wave, waves_per_group, idx_off;
     int32_t E, N, nz, shift_msg, check, write_hard;
-    int32_t vfail_stride_w;
+    int32_t vfail_stride_w, vfail_off_w;
     ChainParams chain;     // check roles only
     int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
 };
@@ -520,8 +537,8 @@ struct FusedParams {
 
 template <int PACK, bool CHAIN, int... Ds>
 __device__ __forceinline__ void fused_cn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *msgs, const uint32_t *state_w,
-                                                uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables) {
-    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables), 0) : 0), ...);
+                                                uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables, uint8_t *hard) {
+    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables, hard), 0) : 0), ...);
 }
 template <int PACK, bool CHECK, int... Ds>
 __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *lds_tab, uint8_t *msgs,
@@ -549,9 +566,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0
         if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     }
     if (P.kind == 0) {
-        // chain fusion exists in the small-degree bucket only (dual-diagonal codes: DVB-S2, IRA) and not with early termination
-        if (BUCKET == 0 && !CHECK && P.chain.on) fused_cn_switch<PACK, BUCKET == 0 && !CHECK>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables);
-        else fused_cn_switch<PACK, false>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables);
+        // chain fusion exists in the small-degree bucket only (dual-diagonal codes: DVB-S2, IRA)
+        if (BUCKET == 0 && (P.chain.on || P.chain.hard)) fused_cn_switch<PACK, BUCKET == 0>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
+        else fused_cn_switch<PACK, false>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
     }
     else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
