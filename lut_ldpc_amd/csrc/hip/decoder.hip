@@ -9,6 +9,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_frontend.hpp"
+#include "kernels_compact.hpp"
 #include "lut_program.hpp"
 #include "jit.hpp"
 
@@ -123,6 +124,11 @@ struct lutldpc_decoder {
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
     int vn_edges_per_wave = 16, cn_edges_per_wave = 42;
     int fused_prio = 0;
+    // compaction of the surviving frames (kernels_compact.hpp): as-shipped mode, skewed pipeline
+    // (off by default: measured on MI355X it does not pay -- DVB-S2 frames finish too late (41.7 of 50 iterations on
+    // average), (3,6) frames finish so close together that whole groups fall idle by themselves; LUTLDPC_COMPACT=1)
+    int use_compact = 0, compact_first = 6, compact_every = 4;
+    DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
     std::vector<std::vector<const JitKernel *>> var_jit, dec_jit, chk_jit;     // [set][class], null = none
@@ -442,6 +448,8 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(d->d_state.alloc((size_t)Bpad));
     HIP_TRY(d->d_vfail.alloc((size_t)Bpad * kVfailSlots * 2));  // two buffers (skewed pipeline: this / next exit test) of kVfailSlots copies, Bcap bytes apart
     HIP_TRY(d->d_iters.alloc((size_t)Bpad));
+    HIP_TRY(d->d_frame_of.alloc((size_t)Bpad)); HIP_TRY(d->d_perm.alloc((size_t)Bpad)); HIP_TRY(d->d_tmp3.alloc((size_t)Bpad * 3));
+    HIP_TRY(d->d_ctl.alloc(8)); HIP_TRY(d->d_slot_of.alloc((size_t)Bpad)); HIP_TRY(d->d_iters_tmp.alloc((size_t)Bpad));
     d->Bcap = Bpad;
     return LUTLDPC_OK;
 }
@@ -731,12 +739,53 @@ int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vect
     return LUTLDPC_OK;
 }
 
+// kernels_compact.hpp: permute the slots of one half (active frames first) right after its exit test of iteration ii
+int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
+    Timed t(d, LUTLDPC_K_LAYOUT);
+    const int T = d->tile(), s0 = h.g0 * T, n = h.G * T;
+    if (n <= 0) return LUTLDPC_OK;
+    uint8_t *pending = d->d_vfail.p + (size_t)((ii + 1) & 1) * kVfailSlots * d->Bcap;      // flags already raised for the next test
+    hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n, T,
+                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, d->d_ctl.p + 4 * hf);
+    const size_t lds = (size_t)4 * h.G * 64 * sizeof(uint32_t);
+    auto rows = [&](uint8_t *buf, int n_rows, int gather) {
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), lds, d->stream, buf, n_rows, n_rows, h.g0, h.G,
+                                            d->d_perm.p, d->d_ctl.p + 4 * hf, gather));
+    };
+    rows(d->d_msgs.p, d->E, 1);
+    rows(d->d_cha_t.p, d->nvar, 1);
+    rows(d->d_hard.p, d->nvar, 0);
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+// end of the decode: decided bits and iteration codes back into the caller's frame order
+int launch_uncompaction(lutldpc_decoder *d, const HalfRange (&half)[2], int Bpad) {
+    Timed t(d, LUTLDPC_K_LAYOUT);
+    hipLaunchKernelGGL(invert_map_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, d->d_slot_of.p, 0, Bpad);
+    for (int hf = 0; hf < 2; hf++) {
+        if (half[hf].G <= 0) continue;
+        const size_t lds = (size_t)4 * half[hf].G * 64 * sizeof(uint32_t);
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3((unsigned)((d->nvar + 3) / 4)), dim3(256), lds, d->stream, d->d_hard.p, d->nvar, d->nvar,
+                                            half[hf].g0, half[hf].G, d->d_slot_of.p, (const int32_t *)nullptr, 0));
+    }
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_iters.p, d->d_slot_of.p, d->d_iters_tmp.p, 0, Bpad);
+    HIP_TRY(hipMemcpyAsync(d->d_iters.p, d->d_iters_tmp.p, sizeof(int32_t) * (size_t)Bpad, hipMemcpyDeviceToDevice, d->stream));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
 // the message-passing iterations of decode_tiles for both halves
 int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
     const int I = d->max_iters, n_ops = 2 * I - 1;
     const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
     const int psc = d->psc ? 1 : 0;
     int rc;
+    const bool compact = psc && d->use_compact;
+    if (compact) {
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
+        LAUNCH_CHECK();
+    }
     for (int slot = 0; slot <= n_ops; slot++) {
         FusedParams FP{};
         FP.prio = d->fused_prio;
@@ -758,6 +807,8 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
         if (state_half >= 0) {                        // :327-329 returns (ii-1)+1
             const int f0 = half[state_half].g0 * d->tile(), f1 = f0 + half[state_half].G * d->tile();
             if ((rc = launch_state(d, B, Bpad, 2, state_ii, f0, f1, state_ii & 1))) return rc;
+            if (compact && state_ii >= d->compact_first && state_ii < I - 1 && (state_ii - d->compact_first) % d->compact_every == 0 &&
+                (rc = launch_compaction(d, half[state_half], state_half, state_ii))) return rc;
         }
     }
     return LUTLDPC_OK;
@@ -809,6 +860,10 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     const int fsel = skewed ? (I & 1) : 0;            // the flag buffer no pass of the skewed pipeline has written since its last test
     if ((rc = launch_syndrome(d, G, fsel))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I, 0, -1, fsel))) return rc;
+    if (skewed && d->psc && d->use_compact) {
+        const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
+        if ((rc = launch_uncompaction(d, half, Bpad))) return rc;
+    }
     if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
     return LUTLDPC_OK;
 }
@@ -922,7 +977,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << d->use_compact << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 
@@ -1004,6 +1059,9 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }
+    if (const char *e = getenv("LUTLDPC_COMPACT_EVERY")) { int v = atoi(e); if (v >= 1) d->compact_every = v; }
     if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
@@ -1036,6 +1094,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();
+        d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release();
         for (auto &kv : d->jit_cache) kv.second.release();
         for (auto &kv : d->item_tabs) kv.second->release();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();

@@ -129,6 +129,24 @@ def test_chain_fusion_is_on_for_the_dual_diagonal_code():
     dec.close()
 
 
+@pytest.mark.parametrize("name,B,snr", [("reg36_n1000_q4", 2100, 1.9), ("n500_q4", 1300, 2.2)])
+def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
+    """LUTLDPC_COMPACT=1: every few iterations the slots of a half are permuted (active frames first) and put back at
+    the end; decided bits, iteration codes and pending flags travel with their frame."""
+    monkeypatch.setenv("LUTLDPC_COMPACT", "1")
+    monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
+    monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "2")
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    assert dec.describe()["compaction"] == 1
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=515)
+    it = _compare(cd, dec, cha, msg, True, True)
+    assert 0 < (it > 0).sum() and len(set(it.tolist())) > 4          # frames finish at many different iterations
+    _compare(cd, dec, cha, msg, True, False)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
 def test_graph_replay_of_repeated_decodes():
     """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
     and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size
