@@ -133,6 +133,9 @@ struct lutldpc_decoder {
     std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
     std::vector<std::vector<const JitKernel *>> var_jit, dec_jit, chk_jit;     // [set][class], null = none
     std::string jit_log;                                               // last hiprtc diagnostic (describe())
+    // LUTLDPC_VALIDATE=1 (debug): every role of a fused launch is checked against the allocation sizes before the launch and
+    // the stream is synchronised after it, so that a device fault is attributed to ONE launch (no graph replay then)
+    int validate = 0;
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
     std::map<std::array<int, 4>, GraphSlot> graphs;       // key {B, psc, pisc, max_iters}
@@ -306,9 +309,47 @@ void build_fast_index(lutldpc_decoder *d) {
     for (char x : internal) d->n_chain_nodes += x;
 }
 
+// Every entry of the dense index tables the specialised kernels read with scalar loads must address a row that exists:
+// variable classes {node < N, first edge + degree <= E}, check classes edge < E, chain links node <= N (0 = none).
+// Always on (O(E) at creation); an inconsistency here would be an out-of-range row in every launch.
+int validate_fast_index(const lutldpc_decoder *d) {
+    const size_t n = d->fast_idx.size();
+    auto bad = [&](const std::string &what) { return fail(LUTLDPC_ERR_STATE, "index table check failed: " + what); };
+    for (size_t i = 0; i < d->vclass.size(); i++) {
+        const auto &c = d->vclass[i];
+        const size_t off = (size_t)d->vn_idx_off[i];
+        if (off + 2 * c.nodes.size() > n) return bad("variable class table outside the blob");
+        for (size_t j = 0; j < c.nodes.size(); j++) {
+            const int v = d->fast_idx[off + 2 * j], e = d->fast_idx[off + 2 * j + 1];
+            if (v < 0 || v >= d->nvar || e < 0 || e + c.deg > d->E) return bad("variable node / first edge out of range");
+        }
+        if (d->vn_red_off[i] >= 0) {
+            const size_t ro = (size_t)d->vn_red_off[i];
+            if (ro + 2 * (size_t)d->vn_red_n[i] > n) return bad("reduced variable class table outside the blob");
+            for (int j = 0; j < d->vn_red_n[i]; j++) {
+                const int v = d->fast_idx[ro + 2 * (size_t)j], e = d->fast_idx[ro + 2 * (size_t)j + 1];
+                if (v < 0 || v >= d->nvar || e < 0 || e + c.deg > d->E) return bad("reduced variable class entry out of range");
+            }
+        }
+    }
+    for (size_t i = 0; i < d->cclass.size(); i++) {
+        const auto &c = d->cclass[i];
+        const size_t off = (size_t)d->cn_idx_off[i], cnt = c.nodes.size() * (size_t)c.deg;
+        if (off + cnt > n) return bad("check class table outside the blob");
+        for (size_t j = 0; j < cnt; j++) if (d->fast_idx[off + j] < 0 || d->fast_idx[off + j] >= d->E) return bad("check edge out of range");
+        if (d->chain_idx_off[i] >= 0) {
+            const size_t co = (size_t)d->chain_idx_off[i];
+            if (co + 2 * c.nodes.size() > n) return bad("chain link table outside the blob");
+            for (size_t j = 0; j < 2 * c.nodes.size(); j++) if (d->fast_idx[co + j] < 0 || d->fast_idx[co + j] > d->nvar) return bad("chain link out of range");
+        }
+    }
+    return LUTLDPC_OK;
+}
+
 int compile_all(lutldpc_decoder *d) {
     std::string err;
     build_fast_index(d);
+    if (int rc = validate_fast_index(d)) return rc;
     // match trees to degree classes like set_trees (src/LDPC_Code_LUT.cpp:133-139,152-158):
     // VARTREE leaves == dv, CHKTREE leaves + 1 == dc, matched on tree set 0
     if (d->var_trees.empty()) return fail(LUTLDPC_ERR_ARG, "no variable-node trees");
@@ -714,6 +755,40 @@ int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::ve
     return LUTLDPC_OK;
 }
 
+// LUTLDPC_VALIDATE: the roles of one fused launch against the sizes of everything they address
+int validate_fused(const lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks) {
+    auto bad = [&](int r, const std::string &what) { return fail(LUTLDPC_ERR_STATE, "fused launch check failed, role " + std::to_string(r) + ": " + what); };
+    if (FP.n_roles < 0 || FP.n_roles > kFusedMaxRoles || (size_t)FP.n_roles != blocks.size()) return bad(-1, "role count");
+    const int groups = d->Bcap / d->tile();
+    const size_t idx_n = d->fast_idx.size(), tab_n = d->d_tables.n, vfail_w = d->d_vfail.n / 4;
+    for (int r = 0; r < FP.n_roles; r++) {
+        const RoleParams &R = FP.role[r];
+        if (R.G < 1 || R.g0 < 0 || R.g0 + R.G > groups) return bad(r, "frame groups outside the batch buffers");
+        if (R.E != d->E || R.N != d->nvar) return bad(r, "E / N");
+        if (R.n_nodes < 1 || R.nodes_per_wave < 1 || R.waves_per_group != (R.n_nodes + R.nodes_per_wave - 1) / R.nodes_per_wave) return bad(r, "waves per group");
+        if (blocks[(size_t)r] != (R.waves_per_group * R.G + 3) / 4) return bad(r, "block count");
+        if (R.vfail_stride_w != d->Bcap / 4 || R.vfail_off_w < 0 || (size_t)R.vfail_off_w + (size_t)kVfailSlots * (size_t)R.vfail_stride_w > vfail_w) return bad(r, "flag buffer");
+        if (R.kind == 0) {
+            if (R.deg < 2 || R.deg > kFusedCnDeg[d->fused_bucket_id]) return bad(r, "check degree outside the bucket");
+            if (R.idx_off < 0 || (size_t)R.idx_off + (size_t)R.n_nodes * (size_t)R.deg > idx_n) return bad(r, "edge table");
+            if (!is_pow2(R.nz) || R.nz > 64) return bad(r, "nz");
+            if (R.chain.on || R.chain.hard) {
+                if (d->fused_bucket_id != 0) return bad(r, "chain fusion outside the first bucket");
+                if (R.chain.idx_off < 0 || (size_t)R.chain.idx_off + 2 * (size_t)R.n_nodes > idx_n) return bad(r, "chain link table");
+                if (R.chain.on && (R.chain.tab_off < 0 || R.chain.tab_len < 4 || R.chain.tab_len > 1024 || (size_t)R.chain.tab_off + (size_t)R.chain.tab_len > tab_n)) return bad(r, "chain table");
+                if (R.chain.on && R.chain.check && (R.chain.vfail_off_w < 0 || (size_t)R.chain.vfail_off_w + (size_t)kVfailSlots * (size_t)R.vfail_stride_w > vfail_w)) return bad(r, "chain flag buffer");
+            }
+        } else {
+            if (R.deg < 1 || R.deg > kFusedVnDeg[d->fused_bucket_id]) return bad(r, "variable degree outside the bucket");
+            if (R.idx_off < 0 || (size_t)R.idx_off + 2 * (size_t)R.n_nodes > idx_n) return bad(r, "node table");
+            const int nt = R.deg >= 3 ? R.deg - 1 : 1;
+            for (int t = 0; t < nt; t++)
+                if (R.tab_off[t] < 0 || R.tab_len[t] < 1 || R.tab_len[t] > kFastTableStride || (R.tab_off[t] & 3) || (size_t)R.tab_off[t] + (size_t)R.tab_len[t] > tab_n) return bad(r, "table " + std::to_string(t));
+        }
+    }
+    return LUTLDPC_OK;
+}
+
 int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, bool vn_check) {
     const int32_t *items = nullptr;
     int nb = 0, rc;
@@ -728,6 +803,7 @@ int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vect
     for (size_t r = 0; r < blocks.size(); r++) front[r] = d->tail_front * cost[r] / (cmax > 0 ? cmax : 1.0);
     if ((rc = item_table(d, blocks, front, &items, &nb))) return rc;
     if (nb == 0) return LUTLDPC_OK;
+    if (d->validate && (rc = validate_fused(d, FP, blocks))) return rc;
     Timed t(d, LUTLDPC_K_FUSED_PASS);
 #define FUSED_ARGS d->stream, FP, items, nb, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), \
                    reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p
@@ -736,6 +812,11 @@ int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vect
     else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
 #undef FUSED_ARGS
     LAUNCH_CHECK();
+    if (d->validate) {                               // attribute a device fault to this launch
+        hipError_t e = hipStreamSynchronize(d->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return fail(LUTLDPC_ERR_HIP, std::string("fused launch failed on the device: ") + hipGetErrorString(e));
+    }
     return LUTLDPC_OK;
 }
 
@@ -1067,6 +1148,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE_CN")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave_cn = v; }
     if (const char *e = getenv("LUTLDPC_SKEW")) d->skew = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_VALIDATE")) { d->validate = atoi(e) ? 1 : 0; if (d->validate) d->use_graph = 0; }
     int rc = compile_all(d.get());
     if (rc) return rc;
     d->skew_ok = skew_eligible(d.get());

@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -30,8 +31,11 @@ static const char *const kCommonHeaderText =
 struct JitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
+    // the code object handed to hipModuleLoadData stays alive as long as the module: the HIP runtime documents no
+    // copy of the image, so it is not freed under a loaded module
+    std::shared_ptr<std::vector<char>> image;
     bool ok() const { return fn != nullptr; }
-    void release() { if (mod) (void)hipModuleUnload(mod); mod = nullptr; fn = nullptr; }
+    void release() { if (mod) (void)hipModuleUnload(mod); mod = nullptr; fn = nullptr; image.reset(); }
 };
 
 constexpr int kJitMaxLdsTable = 48 * 1024;     // class tables above this stay in global memory (L1 / L2 hits)
@@ -324,7 +328,8 @@ inline bool jit_compile(const std::string &src, std::vector<char> &code, std::st
 
 inline bool jit_load(const std::vector<char> &code, JitKernel &k, std::string &log)
 {
-    if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) { log = "hipModuleLoadData failed"; (void)hipGetLastError(); k.mod = nullptr; return false; }
+    k.image = std::make_shared<std::vector<char>>(code);
+    if (hipModuleLoadData(&k.mod, k.image->data()) != hipSuccess) { log = "hipModuleLoadData failed"; (void)hipGetLastError(); k.mod = nullptr; return false; }
     if (hipModuleGetFunction(&k.fn, k.mod, "lutldpc_jit_pass") != hipSuccess) { log = "kernel symbol missing"; (void)hipGetLastError(); k.release(); return false; }
     return true;
 }

@@ -8,6 +8,7 @@
 
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <string>
 
 using namespace lut_ldpc;

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "_build" / "liblut_ldpc_oracle.so"
+_OVERRIDE = os.environ.get("LUTLDPC_ORACLE_LIB")      # a sanitizer build of the same sources (tests/fakehip/Makefile)
 
 
 def build(force: bool = False) -> Path:
@@ -31,8 +32,9 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(str(_LIB_PATH))
+        if not _OVERRIDE:
+            build()
+        L = C.CDLL(_OVERRIDE or str(_LIB_PATH))
         vp, ip, dp, cp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p
         u8p = C.POINTER(C.c_uint8)
         sig = {

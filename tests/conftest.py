@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
 
 
+def pytest_runtest_setup(item):
+    """GPU tests: name the test on the NATIVE stderr before it starts, so that a message of the HIP / HSA runtime (which
+    writes to fd 2 directly and may be the last thing a dying process says) can be attributed to a test in the log."""
+    if item.get_closest_marker("gpu") is not None:
+        try:
+            os.write(2, f"\n[gpu test] {item.nodeid}\n".encode())
+        except OSError:
+            pass
+
+
 @pytest.fixture(scope="session")
 def root():
     return ROOT

@@ -83,3 +83,17 @@ def awgn_labels(cd, B, snr_db, seed, mode=0):
     cha = orc.quant_nonlin(llr, cd.qb_cha)
     msg = orc.quant_nonlin(llr, cd.qb_msg) if mode == 0 else cd.cha2msg_map[cha].astype(np.uint8)
     return cha, msg, llr
+
+
+def compare(cd, dec, cha, msg, psc, pisc, max_iters=None):
+    """Decode the same labels with the oracle and through the C-ABI: every decided bit and every returned iteration
+    code (src/LDPC_Code_LUT.cpp:259-353) must be equal.  Returns the iteration codes."""
+    I = max_iters or cd.max_iters
+    cd.set_exit_conditions(I, psc, pisc)
+    dec.set_exit_conditions(I, psc, pisc)
+    want_bits, want_it = cd.lut_decode_batch(cha, msg)
+    got_bits, got_it = dec.lut_decode_batch(cha, msg)
+    assert (want_it == got_it).all(), (np.flatnonzero(want_it != got_it)[:8], want_it[:8], got_it[:8])
+    bad = np.argwhere(want_bits != got_bits)
+    assert bad.size == 0, f"{len(bad)} bit mismatches, first at frame/bit {bad[:4].tolist()}"
+    return want_it

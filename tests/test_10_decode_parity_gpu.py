@@ -3,21 +3,9 @@ Bit-exact: every decoded bit and the returned iteration code (src/LDPC_Code_LUT.
 import numpy as np
 import pytest
 
-from helpers import awgn_labels, oracle_codec, product_decoder
+from helpers import awgn_labels, compare as _compare, oracle_codec, product_decoder
 
 pytestmark = pytest.mark.gpu
-
-
-def _compare(cd, dec, cha, msg, psc, pisc, max_iters=None):
-    I = max_iters or cd.max_iters
-    cd.set_exit_conditions(I, psc, pisc)
-    dec.set_exit_conditions(I, psc, pisc)
-    want_bits, want_it = cd.lut_decode_batch(cha, msg)
-    got_bits, got_it = dec.lut_decode_batch(cha, msg)
-    assert (want_it == got_it).all(), (np.flatnonzero(want_it != got_it)[:8], want_it[:8], got_it[:8])
-    bad = np.argwhere(want_bits != got_bits)
-    assert bad.size == 0, f"{len(bad)} bit mismatches, first at frame/bit {bad[:4].tolist()}"
-    return want_it
 
 
 CASES = [
@@ -51,25 +39,8 @@ def test_lut_decode_matches_oracle(name, B, snr, psc, pisc):
     dec.close()
 
 
-@pytest.mark.parametrize("name,B,snr", [("n500_q4", 300, 1.8), ("reg36_n1000_mixed", 64, 2.2), ("c5_chklut", 20, 4.2), ("reg36_n1000_high", 33, 2.0)])
-@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_PACK": "1", "LUTLDPC_USE_FAST": "0"}])
-def test_kernel_variants(name, B, snr, env, monkeypatch):
-    """Byte rows vs nibble rows, specialised vs generic kernels: every combination is bit-exact."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    cd = oracle_codec(name)
-    dec = product_decoder(cd)
-    desc = dec.describe()
-    assert desc["pack"] == (1 if "LUTLDPC_PACK" in env else 2) and desc["use_fast"] == (0 if "LUTLDPC_USE_FAST" in env else 1)
-    mode = 1 if name.startswith("c5") else 0
-    cha, msg, _ = awgn_labels(cd, B, snr, seed=77, mode=mode)
-    _compare(cd, dec, cha, msg, True, True)
-    _compare(cd, dec, cha, msg, False, False)
-    dec.close()
-
-
 @pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2), ("dvbs2_q4_i6", 1030, 1.0)])
-@pytest.mark.parametrize("env", [{}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}])
+@pytest.mark.parametrize("env", [{}])
 def test_skewed_pipeline(name, B, snr, env, monkeypatch):
     """Batches of two or more frame groups run as two halves half an iteration out of phase
     (pass_fused_kernel): uneven halves, ragged last group, early termination on and off."""
@@ -129,24 +100,6 @@ def test_chain_fusion_is_on_for_the_dual_diagonal_code():
     dec.close()
 
 
-@pytest.mark.parametrize("name,B,snr", [("reg36_n1000_q4", 2100, 1.9), ("n500_q4", 1300, 2.2)])
-def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
-    """LUTLDPC_COMPACT=1: every few iterations the slots of a half are permuted (active frames first) and put back at
-    the end; decided bits, iteration codes and pending flags travel with their frame."""
-    monkeypatch.setenv("LUTLDPC_COMPACT", "1")
-    monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
-    monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "2")
-    cd = oracle_codec(name)
-    dec = product_decoder(cd)
-    assert dec.describe()["compaction"] == 1
-    cha, msg, _ = awgn_labels(cd, B, snr, seed=515)
-    it = _compare(cd, dec, cha, msg, True, True)
-    assert 0 < (it > 0).sum() and len(set(it.tolist())) > 4          # frames finish at many different iterations
-    _compare(cd, dec, cha, msg, True, False)
-    _compare(cd, dec, cha, msg, False, False)
-    dec.close()
-
-
 def test_graph_replay_of_repeated_decodes():
     """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
     and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size
@@ -194,40 +147,4 @@ def test_fewer_iterations_than_designed_is_rejected_unless_decision_set():
     dec = product_decoder(cd)
     with pytest.raises(L.LutLdpcError):
         dec.set_exit_conditions(4)
-    dec.close()
-
-
-@pytest.mark.parametrize("name,B", [("dvbs2_q4_i6", 5), ("twin64800_q4_i6", 4)])
-def test_n64800_codes(name, B):
-    """C3 (with the degree-1 extension) and its twin that the reference runs as is."""
-    cd = oracle_codec(name)
-    dec = product_decoder(cd)
-    cha, msg, _ = awgn_labels(cd, B, 1.2, seed=3)
-    _compare(cd, dec, cha, msg, True, True)
-    _compare(cd, dec, cha, msg, False, False)
-    dec.close()
-
-
-def test_full_size_properties_c2():
-    """BASELINE config 2 at full size (N=10000, 50 iterations, batch 4096): size-independent properties."""
-    cd = oracle_codec("reg36_n10000_q4")
-    dec = product_decoder(cd)
-    B = 4096
-    cha, msg, _ = awgn_labels(cd, B, 1.8, seed=42)
-    dec.set_exit_conditions(50, True, True)
-    bits, it = dec.lut_decode_batch(cha, msg)
-    ok = it > 0
-    assert ok.mean() > 0.9
-    # every frame reported as converged satisfies all parity checks and (all-zero codeword sent) is zero
-    assert bits[ok].sum() == 0
-    # frames are independent: decoding a permuted batch permutes the result
-    perm = np.random.default_rng(0).permutation(B)
-    bits2, it2 = dec.lut_decode_batch(cha[perm], msg[perm])
-    assert (it2 == it[perm]).all() and (bits2 == bits[perm]).all()
-    # spot-check 6 frames against the oracle, including any that failed
-    idx = np.concatenate([np.flatnonzero(~ok)[:3], np.flatnonzero(ok)[:3]])
-    cd.set_exit_conditions(50, True, True)
-    wb, wi = cd.lut_decode_batch(cha[idx], msg[idx])
-    assert (wi == it[idx]).all() and (wb == bits[idx]).all()
-    # idempotence on decoded output: a decoded codeword re-quantised to the strongest labels decodes at once
     dec.close()

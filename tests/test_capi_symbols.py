@@ -26,3 +26,14 @@ def test_version_and_device_count_without_gpu():
     from lut_ldpc_amd._capi import lib
     assert b"gfx950" in lib.lutldpc_version()
     assert L.device_count() >= 0
+
+
+def test_shipped_library_is_newer_than_its_sources():
+    """lut_ldpc_amd/lib/ is git-ignored and travels to the GPU box as a prebuilt binary: a stale build must not ship."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "lut_ldpc_amd" / "lib" / "liblut_ldpc_amd.so"
+    srcs = [p for p in (root / "lut_ldpc_amd" / "csrc").rglob("*") if p.suffix in (".hip", ".hpp", ".cpp", ".h")] + list((root / "include").glob("*.h"))
+    assert srcs
+    newer = [str(p.relative_to(root)) for p in srcs if p.stat().st_mtime > lib.stat().st_mtime]
+    assert not newer, f"rebuild (make -C lut_ldpc_amd/csrc): newer than the library: {newer}"

@@ -1,0 +1,97 @@
+"""Knob variants (run LAST in the GPU suite: the default configuration is covered by test_00_* / test_10_*).
+
+Size-independent properties at BASELINE.json's full configuration (DVB-S2 N=64800, 4-bit labels, all 50
+iterations), where the oracle is too slow to decode a whole batch: four independent kernel paths must agree bit for
+bit, a batch must decode like its parts, frames must not influence each other, and a few frames are checked against
+the oracle at the full iteration count."""
+import numpy as np
+import pytest
+
+from helpers import awgn_labels, compare as _compare, oracle_codec, product_decoder
+
+pytestmark = pytest.mark.gpu
+
+PATHS = [{}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"},
+         {"LUTLDPC_CHAIN": "0"}, {"LUTLDPC_CN_EDGES_PER_WAVE": "56", "LUTLDPC_PACK": "1"}]
+
+
+def _decode(cd, cha, msg, psc, env, monkeypatch, repeat=1):
+    for k in ("LUTLDPC_SKEW", "LUTLDPC_PACK", "LUTLDPC_USE_FAST", "LUTLDPC_GRAPH", "LUTLDPC_VN_EDGES_PER_WAVE", "LUTLDPC_CHAIN", "LUTLDPC_CN_EDGES_PER_WAVE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dec = product_decoder(cd)
+    dec.set_exit_conditions(cd.max_iters, psc, psc)
+    for _ in range(repeat):
+        bits, it = dec.lut_decode_batch(cha, msg)
+    dec.close()
+    return bits, it
+
+
+@pytest.mark.parametrize("name,snr", [("dvbs2_q4", 1.3), ("reg36_n10000_q4", 1.9)])
+def test_kernel_paths_agree_at_full_iteration_count(name, snr, monkeypatch):
+    cd = oracle_codec(name)
+    assert cd.max_iters == 50
+    B = 1100                                                   # three frame groups: uneven halves, ragged last group
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=2026)
+    for psc in (False, True):
+        # fused two-half pipeline replayed as a graph (third call) is the reference point; on DVB-S2 it runs with chain
+        # fusion (degree-2 parity nodes updated inside the check pass), which PATHS switches off / re-partitions
+        ref_bits, ref_it = _decode(cd, cha, msg, psc, {}, monkeypatch, repeat=3)
+        assert ((ref_it > 0).sum() > 0) and ((np.abs(ref_it) == 50).sum() > 0 or psc)
+        for env in PATHS[1:]:
+            bits, it = _decode(cd, cha, msg, psc, env, monkeypatch)
+            assert (it == ref_it).all(), (env, np.flatnonzero(it != ref_it)[:8])
+            assert (bits == ref_bits).all(), env
+
+
+@pytest.mark.parametrize("name,B,snr", [("n500_q4", 300, 1.8), ("reg36_n1000_mixed", 64, 2.2), ("c5_chklut", 20, 4.2), ("reg36_n1000_high", 33, 2.0)])
+@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_PACK": "1", "LUTLDPC_USE_FAST": "0"}])
+def test_kernel_variants(name, B, snr, env, monkeypatch):
+    """Byte rows vs nibble rows, specialised vs generic kernels: every combination is bit-exact."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    desc = dec.describe()
+    assert desc["pack"] == (1 if "LUTLDPC_PACK" in env else 2) and desc["use_fast"] == (0 if "LUTLDPC_USE_FAST" in env else 1)
+    mode = 1 if name.startswith("c5") else 0
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=77, mode=mode)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
+@pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2)])
+@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_VALIDATE": "1"}])
+def test_skewed_pipeline_variants(name, B, snr, env, monkeypatch):
+    """Byte rows, per-class launches instead of the fused pipeline, and the validating debug mode (every role checked
+    against the allocation sizes, one stream synchronisation per fused launch)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    assert dec.describe()["skewed_pipeline"] == (0 if "LUTLDPC_SKEW" in env else 1)
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=4242)
+    _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, True, False)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
+
+
+@pytest.mark.parametrize("name,B,snr", [("reg36_n1000_q4", 2100, 1.9), ("n500_q4", 1300, 2.2)])
+def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
+    """LUTLDPC_COMPACT=1: every few iterations the slots of a half are permuted (active frames first) and put back at
+    the end; decided bits, iteration codes and pending flags travel with their frame."""
+    monkeypatch.setenv("LUTLDPC_COMPACT", "1")
+    monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
+    monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "2")
+    cd = oracle_codec(name)
+    dec = product_decoder(cd)
+    assert dec.describe()["compaction"] == 1
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=515)
+    it = _compare(cd, dec, cha, msg, True, True)
+    assert 0 < (it > 0).sum() and len(set(it.tolist())) > 4          # frames finish at many different iterations
+    _compare(cd, dec, cha, msg, True, False)
+    _compare(cd, dec, cha, msg, False, False)
+    dec.close()
