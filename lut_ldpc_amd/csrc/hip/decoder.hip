@@ -21,6 +21,7 @@ namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -130,7 +131,8 @@ struct lutldpc_decoder {
     int use_compact = 0, compact_first = 6, compact_every = 4;
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
-    std::map<std::string, JitKernel> jit_cache;                       // source text -> loaded kernel (sets share sources)
+    // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
+    // them and they are never unloaded)
     std::vector<std::vector<const JitKernel *>> var_jit, dec_jit, chk_jit;     // [set][class], null = none
     std::string jit_log;                                               // last hiprtc diagnostic (describe())
     // LUTLDPC_VALIDATE=1 (debug): every role of a fused launch is checked against the allocation sizes before the launch and
@@ -150,7 +152,20 @@ struct lutldpc_decoder {
     int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (needs G >= 2)
     bool skew_ok = false;       // every class of every set has a case in the fused kernel
     int fused_bucket_id = 0;    // degree bucket of the fused kernel (kernels_fast.hpp: kFusedVnDeg / kFusedCnDeg)
-    std::map<std::vector<int>, std::unique_ptr<DevBuf<int32_t>>> item_tabs;   // role block counts -> interleaved item table
+    // launch plan of the skewed pipeline for one (frame groups, psc, max_iters): the roles of every launch in DEVICE memory
+    // (the kernel reads them through a pointer), the interleaved item tables, what follows each launch.  Built once, at
+    // the first decode of that shape; dropped with the batch buffers (the roles hold strides of the flag buffers).
+    struct SkewSlot { int n_roles = 0; size_t role_off = 0; const int32_t *items = nullptr; int nb = 0; int state_half = -1, state_ii = 0; };
+    struct SkewPlan { std::vector<SkewSlot> slots; std::vector<RoleParams> h_roles; DevBuf<RoleParams> d_roles; };
+    std::map<std::array<int, 3>, std::unique_ptr<SkewPlan>> skew_plans;
+    // interleaved item tables, keyed by the role block counts AND the (quantised) share of the timeline each role keeps clear
+    std::map<std::pair<std::vector<int>, std::vector<int>>, std::unique_ptr<DevBuf<int32_t>>> item_tabs;
+    void drop_plans() {
+        for (auto &kv : skew_plans) kv.second->d_roles.release();
+        skew_plans.clear();
+        for (auto &kv : item_tabs) kv.second->release();
+        item_tabs.clear();
+    }
     int tile() const { return kRowBytes * pack; }       // frames per group
     int bpad(int B) const { return (B + tile() - 1) / tile() * tile(); }
     // ---- profiling
@@ -417,6 +432,34 @@ bool fast_covers(const lutldpc_decoder *d, const std::vector<FastClassPlan> &fas
     return d->use_fast && i < fast.size() && fast[i].ok && fast[i].P.deg <= kFastMaxDeg;
 }
 
+// Process-wide registry of the run-time generated kernels, keyed by device + source text.  Decoders share the loaded
+// modules (equal tree shapes give equal sources: no second hiprtc run), and a module is NEVER unloaded while the process
+// lives: unloading frees executable device memory that the runtime hands to the next code object it loads, and the one
+// device fault this library has shown ("The round-1 abort") was the first launch of a lazily loaded code object
+// right after the modules of the previous decoder had been unloaded.  Bounded: beyond kJitRegistryMax distinct sources the
+// generated kernels are simply not used (the interpreter runs instead).
+struct JitRegistry { std::mutex mu; std::map<std::string, JitKernel> by_src; };
+constexpr size_t kJitRegistryMax = 4096;
+JitRegistry &jit_registry() { static JitRegistry *r = new JitRegistry; return *r; }     // never destroyed (see above)
+
+// HIP loads the code object of a translation unit lazily, at the first launch of one of its kernels -- possibly in the
+// middle of a decode and long after other modules came and went.  Load all of them at the first decoder creation on a
+// device instead, while nothing of ours is in flight.
+int preload_code_objects(int device) {
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(done.begin(), done.end(), device) != done.end()) return LUTLDPC_OK;
+    hipFuncAttributes a;
+    HIP_TRY(hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&frame_state_kernel)));             // this translation unit
+    HIP_TRY((preload_fused<2, 0>())); HIP_TRY((preload_fused<2, 1>())); HIP_TRY((preload_fused<2, 2>()));
+    HIP_TRY((preload_vn_fast<TT_VAR, 1>())); HIP_TRY((preload_vn_fast<TT_VAR, 2>())); HIP_TRY((preload_vn_fast<TT_DEC, 2>()));
+    HIP_TRY((preload_cn_fast<2>()));
+    HIP_TRY(hipDeviceSynchronize());
+    done.push_back(device);
+    return LUTLDPC_OK;
+}
+
 // jit.hpp: generate + compile + load a kernel for every variable / decision / CHKTREE class without a
 // compile-time specialised one
 void build_jit(lutldpc_decoder *d) {
@@ -438,21 +481,26 @@ void build_jit(lutldpc_decoder *d) {
                 const bool gen = kind == TT_CHK ? jit_cn_source(progs[i], cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err)
                                                 : jit_vn_source(progs[i], kind, cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err);
                 if (!gen) { d->jit_log = err; continue; }
-                auto it = d->jit_cache.find(src);
-                if (it == d->jit_cache.end()) {
+                JitRegistry &reg = jit_registry();
+                std::lock_guard<std::mutex> lock(reg.mu);
+                const std::string key = std::to_string(d->device) + "\n" + src;
+                auto it = reg.by_src.find(key);
+                if (it == reg.by_src.end()) {
+                    if (reg.by_src.size() >= kJitRegistryMax) { d->jit_log = "generated-kernel registry full"; continue; }
                     std::vector<char> code;
                     JitKernel k;
                     std::string log;
-                    if (!jit_compile(src, code, log) || !jit_load(code, k, log)) { d->jit_log = log; d->jit_cache[src] = JitKernel(); continue; }
-                    it = d->jit_cache.emplace(src, k).first;
+                    if (!jit_compile(src, code, log) || !jit_load(code, k, log)) { d->jit_log = log; reg.by_src[key] = JitKernel(); continue; }
+                    it = reg.by_src.emplace(key, k).first;
                 }
-                if (it->second.ok()) out[i] = &it->second;
+                if (it->second.ok()) out[i] = &it->second;        // (std::map nodes are stable: the pointer outlives the lock)
             }
         }
 }
 
 int upload_static(lutldpc_decoder *d) {
     HIP_TRY(hipSetDevice(d->device));
+    if (int rc = preload_code_objects(d->device)) return rc;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIP_TRY(d->d_vn_ptr.upload(d->vn_ptr));
     HIP_TRY(d->d_cn_ptr.upload(d->cn_ptr));
@@ -481,7 +529,8 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     int Bpad = d->bpad(B);
     if (Bpad <= d->Bcap) return LUTLDPC_OK;
     size_t G = (size_t)(Bpad / d->tile());
-    d->drop_graphs();                                // the captured launches hold the old buffer addresses
+    d->drop_graphs();                                // the captured launches hold the old buffer addresses,
+    d->drop_plans();                                 // the launch plans the strides of the flag buffers
     HIP_TRY(d->d_msgs.alloc(G * (size_t)d->E * kRowBytes));
     HIP_TRY(d->d_cha_t.alloc(G * (size_t)d->nvar * kRowBytes));
     HIP_TRY(d->d_msg0_t.alloc(G * (size_t)d->nvar * kRowBytes));
@@ -735,7 +784,10 @@ int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::ve
     int nb = 0;
     for (int b : blocks) nb += b;
     *total = nb;
-    auto it = d->item_tabs.find(blocks);
+    std::vector<int> fq(front.size());
+    for (size_t r = 0; r < front.size(); r++) fq[r] = (int)(front[r] * 4096.0);
+    const auto key = std::make_pair(blocks, fq);
+    auto it = d->item_tabs.find(key);
     if (it == d->item_tabs.end()) {
         std::vector<std::pair<double, std::pair<int, int>>> pos;
         pos.reserve((size_t)nb);
@@ -749,7 +801,7 @@ int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::ve
         for (auto &q : pos) { h.push_back(q.second.first); h.push_back(q.second.second); }
         std::unique_ptr<DevBuf<int32_t>> buf(new DevBuf<int32_t>());
         HIP_TRY(buf->upload(h));
-        it = d->item_tabs.emplace(blocks, std::move(buf)).first;
+        it = d->item_tabs.emplace(key, std::move(buf)).first;
     }
     *out = it->second->p;
     return LUTLDPC_OK;
@@ -789,10 +841,9 @@ int validate_fused(const lutldpc_decoder *d, const FusedParams &FP, const std::v
     return LUTLDPC_OK;
 }
 
-int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, bool vn_check) {
-    const int32_t *items = nullptr;
-    int nb = 0, rc;
-    // per-wave work of a role ~ edges per wave, a variable-node edge costing about 3x a check edge (LUT look-ups)
+// the item table of one launch: per-wave work of a role ~ edges per wave, a variable-node edge costing about 3x a check
+// edge (LUT look-ups); the slow roles keep clear of the end of the launch (item_table)
+int plan_items(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, const int32_t **items, int *nb) {
     std::vector<double> cost(blocks.size()), front(blocks.size());
     double cmax = 0;
     for (size_t r = 0; r < blocks.size(); r++) {
@@ -801,12 +852,14 @@ int launch_fused_pass(lutldpc_decoder *d, const FusedParams &FP, const std::vect
         cmax = std::max(cmax, cost[r]);
     }
     for (size_t r = 0; r < blocks.size(); r++) front[r] = d->tail_front * cost[r] / (cmax > 0 ? cmax : 1.0);
-    if ((rc = item_table(d, blocks, front, &items, &nb))) return rc;
-    if (nb == 0) return LUTLDPC_OK;
-    if (d->validate && (rc = validate_fused(d, FP, blocks))) return rc;
+    return item_table(d, blocks, front, items, nb);
+}
+
+int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan, const lutldpc_decoder::SkewSlot &sl, bool vn_check) {
+    if (sl.nb == 0) return LUTLDPC_OK;
     Timed t(d, LUTLDPC_K_FUSED_PASS);
-#define FUSED_ARGS d->stream, FP, items, nb, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), \
-                   reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p
+#define FUSED_ARGS d->stream, plan.d_roles.p + sl.role_off, sl.items, sl.nb, d->fused_prio, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, \
+                   reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p
     if (d->fused_bucket_id == 0) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 0>(FUSED_ARGS)));
     else if (d->fused_bucket_id == 1) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 1>(FUSED_ARGS)));
     else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
@@ -855,23 +908,18 @@ int launch_uncompaction(lutldpc_decoder *d, const HalfRange (&half)[2], int Bpad
     return LUTLDPC_OK;
 }
 
-// the message-passing iterations of decode_tiles for both halves
-int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
+// Build (once per shape) the launch plan of the message-passing iterations of both halves: slot s pairs pass s of half A
+// with pass s-1 of half B, a pass being CN(ii) for even and VN(ii) for odd numbers.  Every role is checked against the
+// sizes of what it addresses before the plan is accepted (validate_fused), the roles then move to device memory once.
+int build_skew_plan(lutldpc_decoder *d, int G, lutldpc_decoder::SkewPlan &plan) {
     const int I = d->max_iters, n_ops = 2 * I - 1;
     const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
     const int psc = d->psc ? 1 : 0;
     int rc;
-    const bool compact = psc && d->use_compact;
-    if (compact) {
-        Timed t(d, LUTLDPC_K_LAYOUT);
-        hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
-        LAUNCH_CHECK();
-    }
     for (int slot = 0; slot <= n_ops; slot++) {
         FusedParams FP{};
-        FP.prio = d->fused_prio;
         std::vector<int> blocks;
-        int state_half = -1, state_ii = 0;
+        lutldpc_decoder::SkewSlot sl;
         for (int hf = 0; hf < 2; hf++) {
             const int op = slot - hf;                 // B lags by one pass
             if (op < 0 || op >= n_ops) continue;
@@ -879,17 +927,51 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
             if ((op & 1) == 0) {                      // CN(ii)
                 const int check = (psc && ii > 0) ? 1 : 0;
                 add_cn_roles(d, FP, blocks, half[hf], ii, check);
-                if (check) { state_half = hf; state_ii = ii; }
+                if (check) { sl.state_half = hf; sl.state_ii = ii; }
             } else {                                  // VN(ii)
                 add_vn_roles(d, FP, blocks, half[hf], ii, psc, psc);
             }
         }
-        if ((rc = launch_fused_pass(d, FP, blocks, psc != 0))) return rc;
-        if (state_half >= 0) {                        // :327-329 returns (ii-1)+1
-            const int f0 = half[state_half].g0 * d->tile(), f1 = f0 + half[state_half].G * d->tile();
-            if ((rc = launch_state(d, B, Bpad, 2, state_ii, f0, f1, state_ii & 1))) return rc;
-            if (compact && state_ii >= d->compact_first && state_ii < I - 1 && (state_ii - d->compact_first) % d->compact_every == 0 &&
-                (rc = launch_compaction(d, half[state_half], state_half, state_ii))) return rc;
+        // roles without work (an empty half when G == 1 never gets here; a degree class emptied by chain fusion does)
+        FusedParams FQ{};
+        std::vector<int> bq;
+        for (int r = 0; r < FP.n_roles; r++) if (blocks[(size_t)r] > 0) { FQ.role[FQ.n_roles++] = FP.role[r]; bq.push_back(blocks[(size_t)r]); }
+        if ((rc = validate_fused(d, FQ, bq))) return rc;
+        if ((rc = plan_items(d, FQ, bq, &sl.items, &sl.nb))) return rc;
+        sl.n_roles = FQ.n_roles; sl.role_off = plan.h_roles.size();
+        plan.h_roles.insert(plan.h_roles.end(), FQ.role, FQ.role + FQ.n_roles);
+        plan.slots.push_back(sl);
+    }
+    HIP_TRY(plan.d_roles.upload(plan.h_roles));
+    return LUTLDPC_OK;
+}
+
+// the message-passing iterations of decode_tiles for both halves
+int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
+    const int I = d->max_iters;
+    const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
+    const int psc = d->psc ? 1 : 0;
+    int rc;
+    auto &pp = d->skew_plans[{G, psc, I}];
+    if (!pp) {
+        std::unique_ptr<lutldpc_decoder::SkewPlan> np(new lutldpc_decoder::SkewPlan());
+        if ((rc = build_skew_plan(d, G, *np))) { np->d_roles.release(); d->skew_plans.erase({G, psc, I}); return rc; }
+        pp = std::move(np);
+    }
+    const lutldpc_decoder::SkewPlan &plan = *pp;
+    const bool compact = psc && d->use_compact;
+    if (compact) {
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
+        LAUNCH_CHECK();
+    }
+    for (const auto &sl : plan.slots) {
+        if ((rc = launch_fused_slot(d, plan, sl, psc != 0))) return rc;
+        if (sl.state_half >= 0) {                     // :327-329 returns (ii-1)+1
+            const int f0 = half[sl.state_half].g0 * d->tile(), f1 = f0 + half[sl.state_half].G * d->tile();
+            if ((rc = launch_state(d, B, Bpad, 2, sl.state_ii, f0, f1, sl.state_ii & 1))) return rc;
+            if (compact && sl.state_ii >= d->compact_first && sl.state_ii < I - 1 && (sl.state_ii - d->compact_first) % d->compact_every == 0 &&
+                (rc = launch_compaction(d, half[sl.state_half], sl.state_half, sl.state_ii))) return rc;
         }
     }
     return LUTLDPC_OK;
@@ -1177,8 +1259,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();
         d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release();
-        for (auto &kv : d->jit_cache) kv.second.release();
-        for (auto &kv : d->item_tabs) kv.second->release();
+        d->drop_plans();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
     }

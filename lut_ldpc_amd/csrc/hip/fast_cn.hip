@@ -3,4 +3,5 @@
 namespace lutldpc {
 template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);
 template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);
+template hipError_t preload_cn_fast<2>();
 }

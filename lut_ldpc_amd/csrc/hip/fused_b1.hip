@@ -3,4 +3,5 @@
 namespace lutldpc {
 template void launch_fused<1, 1> LUTLDPC_FUSED_SIG;
 template void launch_fused<2, 1> LUTLDPC_FUSED_SIG;
+template hipError_t preload_fused<2, 1>();
 }

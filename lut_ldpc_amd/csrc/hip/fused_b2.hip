@@ -3,4 +3,5 @@
 namespace lutldpc {
 template void launch_fused<1, 2> LUTLDPC_FUSED_SIG;
 template void launch_fused<2, 2> LUTLDPC_FUSED_SIG;
+template hipError_t preload_fused<2, 2>();
 }

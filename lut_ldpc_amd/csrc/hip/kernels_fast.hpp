@@ -529,6 +529,8 @@ struct RoleParams {
     ChainParams chain;     // check roles only
     int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
 };
+// host-side staging of the roles of one launch (decoder.hip builds these once per (batch shape, exit conditions) and keeps
+// them in DEVICE memory: the kernel gets a pointer, not the 3.4 KB by value)
 struct FusedParams {
     int32_t n_roles;
     int32_t prio;          // 1: raise the issue priority of the look-up-heavy waves (s_setprio)
@@ -547,22 +549,20 @@ __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, 
     ((P.deg == Ds + 1 ? (vn_balanced_body<Ds + 1, TT_VAR, CHECK, PACK>(P, block, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), 0) : 0), ...);
 }
 
-// items[b] = {role, block index within the role}
+// items[b] = {role, block index within the role}; roles[] = the roles of THIS launch, in device memory (read-only
+// for the whole decode: the role is picked with a wave-uniform run-time index, its fields come in through scalar
+// loads as they are needed).  The kernel-argument segment stays a handful of pointers.
 template <int PACK, bool CHECK, int BUCKET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? 7 : BUCKET == 1 ? 4 : 3, 8))) void pass_fused_kernel(
-    FusedParams FP, const int2 *__restrict__ items, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
+    const RoleParams *__restrict__ roles, const int2 *__restrict__ items, int prio, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)
 {
     constexpr int MAXVN = kFusedVnDeg[BUCKET], MAXCN = kFusedCnDeg[BUCKET];
     __shared__ __attribute__((aligned(16))) uint8_t lds_tab[MAXVN * kFastTableStride];
     const int2 it = items[blockIdx.x];
     const int r = __builtin_amdgcn_readfirstlane(it.x), rb = __builtin_amdgcn_readfirstlane(it.y);
-    // the role is picked with a run-time index: read it straight from the kernel-argument segment (scalar
-    // loads from constant memory) -- indexing the by-value struct would make the compiler copy all of it
-    // to scratch memory first
-    const FusedParams *kernarg = (const FusedParams *)__builtin_amdgcn_kernarg_segment_ptr();    // FP is the first argument
-    const RoleParams &P = kernarg->role[r];
-    if (FP.prio && P.kind) {                       // LUT-heavy waves first: they are the long ones
+    const RoleParams &P = roles[r];
+    if (prio && P.kind) {                          // LUT-heavy waves first: they are the long ones
         if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     }
     if (P.kind == 0) {
@@ -718,19 +718,38 @@ bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int
     return dispatch_cn_fast<PACK>(deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, msgs, state_w, vfail_w, fast_idx);
 }
 
-// skewed pipeline: one launch of pass_fused_kernel over n_blocks items
-template <int PACK, int BUCKET>
-void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, int n_blocks, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
-                  const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
-    if (vn_check)
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, true, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx);
-    else
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, false, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, FP, reinterpret_cast<const int2 *>(items), msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx);
+// code-object preload of the per-class translation units (see preload_fused)
+template <int KIND, int PACK>
+hipError_t preload_vn_fast() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&vn_balanced_fast_kernel<2, KIND, false, PACK>));
+}
+template <int PACK>
+hipError_t preload_cn_fast() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&cn_minsum_fast_kernel<2, 4, PACK>));
 }
 
-#define LUTLDPC_FUSED_SIG (hipStream_t, const FusedParams &, const int32_t *, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *)
+// skewed pipeline: one launch of pass_fused_kernel over n_blocks items
+template <int PACK, int BUCKET>
+void launch_fused(hipStream_t s, const RoleParams *d_roles, const int32_t *items, int n_blocks, int prio, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
+                  const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
+    if (vn_check)
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, true, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
+                           state_w, vfail_w, tables, fast_idx);
+    else
+        hipLaunchKernelGGL((pass_fused_kernel<PACK, false, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
+                           state_w, vfail_w, tables, fast_idx);
+}
+// force the code object of this translation unit onto the current device now (HIP loads code objects lazily, at the first
+// launch of one of their kernels): decoder.hip calls these at decoder creation, see preload_code_objects
+template <int PACK, int BUCKET>
+hipError_t preload_fused() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&pass_fused_kernel<PACK, false, BUCKET>));
+}
+
+#define LUTLDPC_FUSED_SIG (hipStream_t, const RoleParams *, const int32_t *, int, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *)
 #define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
     X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
     X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
@@ -740,6 +759,9 @@ void launch_fused(hipStream_t s, const FusedParams &FP, const int32_t *items, in
     X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
     X template void launch_fused<1, 0> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 0> LUTLDPC_FUSED_SIG; \
     X template void launch_fused<1, 1> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 1> LUTLDPC_FUSED_SIG; \
-    X template void launch_fused<1, 2> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 2> LUTLDPC_FUSED_SIG;
+    X template void launch_fused<1, 2> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 2> LUTLDPC_FUSED_SIG; \
+    X template hipError_t preload_fused<2, 0>(); X template hipError_t preload_fused<2, 1>(); X template hipError_t preload_fused<2, 2>(); \
+    X template hipError_t preload_vn_fast<TT_VAR, 1>(); X template hipError_t preload_vn_fast<TT_VAR, 2>(); X template hipError_t preload_vn_fast<TT_DEC, 2>(); \
+    X template hipError_t preload_cn_fast<2>();
 
 }  // namespace lutldpc
