@@ -34,6 +34,12 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# LUT designs are kept between runs (lut_ldpc_amd/csrc/host/ldpc_code_lut.cpp, "design cache"): set-up, never timed
+os.environ.setdefault("LUTLDPC_DESIGN_CACHE", str(ROOT / "data" / "design_cache"))
+try:
+    Path(os.environ["LUTLDPC_DESIGN_CACHE"]).mkdir(parents=True, exist_ok=True)
+except OSError:
+    pass
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -73,9 +79,82 @@ def make_labels(cd, B, snr_db, seed, qcha_map=None):
     return cha, msg
 
 
-def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=15.0):
-    """The oracle (single-threaded restatement of the reference's per-output queue/recursion decoder)
-    on a bounded sample of the same labels.  Tables are handed over as the reference's tree text."""
+def make_labels_device(cd, B, snr_db, seed, qcha_map=None):
+    """The same synthetic frames generated in HBM (torch's Philox normal generator + bucketize = quant_nonlin): a 16384-frame
+    DVB-S2 batch is 10^9 samples, which numpy needs ~20 s for.  Untimed set-up either way; the CPU baseline decodes a copy of
+    the first frames of exactly these labels."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    N0 = 10 ** (-snr_db / 10) / cd.rate
+    qc = torch.from_numpy(np.ascontiguousarray(cd.qb_cha)).cuda()
+    qm = torch.from_numpy(np.ascontiguousarray(cd.qb_msg)).cuda()
+    qmap = None if qcha_map is None else torch.from_numpy(np.ascontiguousarray(qcha_map, np.uint8)).cuda()
+    cha = torch.empty((B, cd.nvar), dtype=torch.uint8, device="cuda")
+    msg = torch.empty((B, cd.nvar), dtype=torch.uint8, device="cuda")
+    step = max(1, (1 << 27) // cd.nvar)
+    for b0 in range(0, B, step):
+        n = min(step, B - b0)
+        llr = (1.0 + torch.randn((n, cd.nvar), generator=g, device="cuda", dtype=torch.float64) * float(np.sqrt(N0 / 2))) * (4.0 / N0)
+        c = torch.bucketize(llr, qc, right=False)            # number of boundaries strictly below the value (src/common.cpp:120-129)
+        cha[b0:b0 + n] = c.to(torch.uint8)
+        msg[b0:b0 + n] = torch.bucketize(llr, qm, right=False).to(torch.uint8) if qmap is None else qmap[c]
+    return cha, msg
+
+
+class PowerSampler:
+    """Socket power and shader clock from the amdgpu hwmon files, sampled by a thread while the GPU works (a few ms per
+    sample, no GPU access).  Identical runs land on discrete throughput levels per process; the
+    samples say whether a level comes with a different clock or power.  Silent when the files are not there."""
+
+    def __init__(self, period_s=0.01):
+        import glob
+        self.period = period_s
+        self.power = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))[:1]
+        self.sclk = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))[:1]
+        self.samples = []
+        self._stop = False
+        self._thr = None
+
+    def _read(self, paths):
+        try:
+            return float(open(paths[0]).read().split()[0]) if paths else None
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append((time.perf_counter(), self._read(self.power), self._read(self.sclk)))
+                time.sleep(self.period)
+        if self.power or self.sclk:
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._thr:
+            self._thr.join()
+
+    def summary(self):
+        pw = [p * 1e-6 for _, p, _ in self.samples if p is not None]
+        ck = [c * 1e-6 for _, _, c in self.samples if c is not None]
+        if not pw and not ck:
+            return None
+        q = lambda v, f: float(np.percentile(v, f)) if v else None
+        return {"samples": len(self.samples), "socket_power_W": {"median": q(pw, 50), "p10": q(pw, 10), "p90": q(pw, 90)},
+                "sclk_MHz": {"median": q(ck, 50), "p10": q(ck, 10), "p90": q(ck, 90)}}
+
+
+def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=9.0):
+    """SURVEY 8(d), both CPU legs, on bounded samples of the same labels on this host's cores:
+    (i) the oracle in FAITHFUL mode -- the reference's structure (per-output queue copy + recursive tree walk, one
+        thread: ber_sim is single-threaded);
+    (ii) the oracle in FLAT-TABLE mode (oracle/or_flat.c: trees flattened to arrays, one frame per thread, all cores).
+    Tables are handed over as the reference's tree text.  Returns the JSON object and the decoded sample of leg (i)."""
     from oracle import oracle as orc
     code = orc.Code(ROOT / "data" / "codes" / f"{cd.alist}.alist")
     oc = orc.Codec(code, skip_rank=True)
@@ -89,9 +168,22 @@ def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=15.0):
     t0 = time.perf_counter()
     bits, iters = oc.lut_decode_batch(cha[:n], msg[:n])
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "codewords/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of the same labels, oracle faithful mode (per-output queue copy + recursive tree walk), "
-                      f"{dt:.1f} s on this host"}, bits, iters
+    faithful = {"value": n / dt, "unit": "codewords/s", "cores": 1,
+                "sample": f"{n} frames, oracle faithful mode (per-output queue copy + recursive tree walk), {dt:.1f} s"}
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oc.lut_decode_batch_flat(cha[:cores], msg[:cores], threads=cores)
+    t1 = (time.perf_counter() - t0) / 1.0
+    nf = int(max(cores, min(len(cha), cores * budget_s / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    fb, fi = oc.lut_decode_batch_flat(cha[:nf], msg[:nf], threads=cores)
+    dtf = time.perf_counter() - t0
+    m = min(n, nf)
+    flat = {"value": nf / dtf, "unit": "codewords/s", "cores": cores,
+            "sample": f"{nf} frames, oracle flat-table mode (trees flattened to arrays, one frame per thread), {dtf:.1f} s",
+            "matches_faithful_mode": bool((fb[:m] == bits[:m]).all() and (fi[:m] == iters[:m]).all())}
+    return {"value": flat["value"], "unit": "codewords/s", "cores": cores, "kind": "port",
+            "sample": flat["sample"] + f"; nproc = {cores}", "faithful_1core": faithful, "flat_allcores": flat}, bits, iters, fb, fi
 
 
 def main():
@@ -105,6 +197,7 @@ def main():
                     help="fixed: parity_check_iter=false (all iterations); shipped: syndrome checks + early termination")
     ap.add_argument("--snr", type=float, default=None, help="Eb/N0 in dB of the synthetic frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reps", type=int, default=7, help="extra single steps, each timed on its own, for the median / spread of a step (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not bracket the kernels with HIP events")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--frame-loop-steps", type=int, default=2, help="extra untimed-for-`value` steps of the full sampler+decode+count loop (0 = skip)")
@@ -150,9 +243,9 @@ def main():
     if args.workload.startswith("c5"):
         cd.set_initial_message_mode(1)
         qcha_map = np.asarray(cd.cha2msg_map, np.uint8)
-    cha_h, msg_h = make_labels(cd, B, snr, seed=1234 + rank, qcha_map=qcha_map)
-    cha = torch.from_numpy(cha_h).cuda()
-    msg = torch.from_numpy(msg_h).cuda()
+    cha, msg = make_labels_device(cd, B, snr, seed=1234 + rank, qcha_map=qcha_map)
+    n_host = min(B, 4096)                                      # what the CPU baseline may sample from
+    cha_h, msg_h = cha[:n_host].cpu().numpy(), msg[:n_host].cpu().numpy()
     out_bits = torch.empty((B, N), dtype=torch.uint8, device="cuda")
     out_iters = torch.empty(B, dtype=torch.int32, device="cuda")
     counters = torch.zeros(5, dtype=torch.int64, device="cuda")   # frames, data bits, frame errs, bit errs, uncoded errs
@@ -196,6 +289,19 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # ---- single steps, each timed on its own (after the timed region, never part of `value`): median and spread of a step
+    # inside this process, with socket power and shader clock sampled meanwhile
+    step_stats = None
+    if args.reps > 0:
+        ts = []
+        with PowerSampler() as ps:
+            for _ in range(args.reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step(True)
+                ts.append((time.perf_counter() - t1) * 1e3)
+        step_stats = {"reps": args.reps, "median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "max_ms": float(max(ts)),
+                      "codewords_per_s_at_median": B / (float(np.median(ts)) * 1e-3), "power_clock": ps.summary()}
     # ---- the same K steps again with every launch bracketed by HIP events on the decoder's stream: the
     # per-kernel durations behind `roofline` (events cannot sit inside a graph replay, so this pass issues
     # plain launches; its own wall time is reported as ms_per_step_instrumented, never as `value`)
@@ -283,6 +389,7 @@ def main():
                                   "device_copy_GBps_measured": copy_gbps},
         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
         "decode_ms_per_step_host_clock": t_decode / args.steps * 1e3,
+        "single_steps": step_stats,
         "ms_per_step_instrumented": None if args.no_kernel_events else dt_instr / args.steps * 1e3,
         "counters": {"frames": int(counters[0]), "data_bits": int(counters[1]), "frame_errors": int(counters[2]),
                      "data_bit_errors": int(counters[3]), "uncoded_bit_errors": int(counters[4])},
@@ -304,10 +411,12 @@ def main():
                                 "frame_errors_last_step": int((st[:, 1] != 0).sum()),
                                 "note": "device sampler (Philox4x32-10 cell sampler) + decode + BER/FER counting, zero codeword"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ob, oi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
-        n = len(oi)
-        same = bool((ob == out_bits[:n].cpu().numpy()).all() and (oi == out_iters[:n].cpu().numpy()).all())
+        base, ob, oi, fb, fi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
+        n, nf = len(oi), len(fi)
+        same = bool((ob == out_bits[:n].cpu().numpy()).all() and (oi == out_iters[:n].cpu().numpy()).all()
+                    and (fb == out_bits[:nf].cpu().numpy()).all() and (fi == out_iters[:nf].cpu().numpy()).all())
         base["gpu_matches_oracle_on_sample"] = same
+        base["frames_compared_with_gpu"] = int(max(n, nf))
         result["cpu_baseline"] = base
         if not same:
             raise SystemExit("GPU output differs from the oracle on the cpu_baseline sample")

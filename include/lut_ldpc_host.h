@@ -33,6 +33,10 @@ int lutldpc_codec_destroy(lutldpc_codec *c);
 int lutldpc_codec_design_luts(lutldpc_codec *c, const char *tree_method, int min_lut, double sigma2, int max_iters,
                               const uint8_t *reuse_vec, int Nq_Cha, const int32_t *Nq_Msg, int allow_degree_one,
                               double *sigma_out);
+/* 1 when the last design_luts was read from the design cache (environment LUTLDPC_DESIGN_CACHE=<directory>: designs are
+ * kept there keyed by a hash of every design input, trees in the reference's own text serialisation,
+ * src/LUT_Tree.cpp:847-865), 0 when density evolution ran. */
+int lutldpc_codec_design_from_cache(lutldpc_codec *c);
 int lutldpc_codec_set_exit_conditions(lutldpc_codec *c, int max_iters, int psc, int pisc);
 int lutldpc_codec_set_initial_message_mode(lutldpc_codec *c, int mode);   /* 0 CONT, 1 QCHA */
 int lutldpc_codec_set_output_verbosity(lutldpc_codec *c, int level);

@@ -83,6 +83,7 @@ _HOST_SIGNATURES = {
     "lutldpc_codec_save": (C.c_int, [_vp, _cp]),
     "lutldpc_codec_destroy": (C.c_int, [_vp]),
     "lutldpc_codec_design_luts": (C.c_int, [_vp, _cp, C.c_int, C.c_double, C.c_int, _u8p, C.c_int, _ip, C.c_int, _dp]),
+    "lutldpc_codec_design_from_cache": (C.c_int, [_vp]),
     "lutldpc_codec_set_exit_conditions": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "lutldpc_codec_set_initial_message_mode": (C.c_int, [_vp, C.c_int]),
     "lutldpc_codec_set_output_verbosity": (C.c_int, [_vp, C.c_int]),

@@ -47,6 +47,7 @@ class Codec:
         check(lib.lutldpc_codec_design_luts(self._h, tree_method.encode(), int(min_lut), float(sigma2), int(max_iters),
                                             _p(reuse, C.c_uint8), int(nq_cha), _p(nq, C.c_int32), int(allow_degree_one), C.byref(sig)))
         self.max_iters = max_iters
+        self.design_from_cache = bool(lib.lutldpc_codec_design_from_cache(self._h))   # LUTLDPC_DESIGN_CACHE=<dir>
         return sig.value
 
     def set_exit_conditions(self, max_iters, psc=True, pisc=False):

@@ -138,6 +138,7 @@ struct lutldpc_decoder {
     // LUTLDPC_VALIDATE=1 (debug): every role of a fused launch is checked against the allocation sizes before the launch and
     // the stream is synchronised after it, so that a device fault is attributed to ONE launch (no graph replay then)
     int validate = 0;
+    int sweep_reverse = 0;      // LUTLDPC_REVERSE: alternate the sweep direction over the frame groups between launches
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
     std::map<std::array<int, 4>, GraphSlot> graphs;       // key {B, psc, pisc, max_iters}
@@ -780,12 +781,15 @@ void add_vn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
 
 // interleave the blocks of all roles evenly over the launch: block j of a role with n blocks sits at
 // position (j + 1/2) / n of the timeline
-int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::vector<double> &front, const int32_t **out, int *total) {
+// `reverse`: the blocks of every role in descending order (the sweep over the frame groups runs backwards: see
+// build_skew_plan)
+int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::vector<double> &front, bool reverse, const int32_t **out, int *total) {
     int nb = 0;
     for (int b : blocks) nb += b;
     *total = nb;
     std::vector<int> fq(front.size());
     for (size_t r = 0; r < front.size(); r++) fq[r] = (int)(front[r] * 4096.0);
+    fq.push_back(reverse ? 1 : 0);
     const auto key = std::make_pair(blocks, fq);
     auto it = d->item_tabs.find(key);
     if (it == d->item_tabs.end()) {
@@ -794,7 +798,7 @@ int item_table(lutldpc_decoder *d, const std::vector<int> &blocks, const std::ve
         // `front[r]` in [0,1): roles with long-running blocks are issued over [0, 1 - front) only, so that the
         // launch does not end on a tail of a few slow blocks (the next launch needs this one complete)
         for (size_t r = 0; r < blocks.size(); r++)
-            for (int j = 0; j < blocks[r]; j++) pos.push_back({((double)j + 0.5) / (double)blocks[r] * (1.0 - front[r]), {(int)r, j}});
+            for (int j = 0; j < blocks[r]; j++) pos.push_back({((double)j + 0.5) / (double)blocks[r] * (1.0 - front[r]), {(int)r, reverse ? blocks[r] - 1 - j : j}});
         std::stable_sort(pos.begin(), pos.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
         std::vector<int32_t> h;
         h.reserve(2 * (size_t)nb);
@@ -843,7 +847,7 @@ int validate_fused(const lutldpc_decoder *d, const FusedParams &FP, const std::v
 
 // the item table of one launch: per-wave work of a role ~ edges per wave, a variable-node edge costing about 3x a check
 // edge (LUT look-ups); the slow roles keep clear of the end of the launch (item_table)
-int plan_items(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, const int32_t **items, int *nb) {
+int plan_items(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int> &blocks, bool reverse, const int32_t **items, int *nb) {
     std::vector<double> cost(blocks.size()), front(blocks.size());
     double cmax = 0;
     for (size_t r = 0; r < blocks.size(); r++) {
@@ -852,7 +856,7 @@ int plan_items(lutldpc_decoder *d, const FusedParams &FP, const std::vector<int>
         cmax = std::max(cmax, cost[r]);
     }
     for (size_t r = 0; r < blocks.size(); r++) front[r] = d->tail_front * cost[r] / (cmax > 0 ? cmax : 1.0);
-    return item_table(d, blocks, front, items, nb);
+    return item_table(d, blocks, front, reverse, items, nb);
 }
 
 int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan, const lutldpc_decoder::SkewSlot &sl, bool vn_check) {
@@ -937,7 +941,9 @@ int build_skew_plan(lutldpc_decoder *d, int G, lutldpc_decoder::SkewPlan &plan) 
         std::vector<int> bq;
         for (int r = 0; r < FP.n_roles; r++) if (blocks[(size_t)r] > 0) { FQ.role[FQ.n_roles++] = FP.role[r]; bq.push_back(blocks[(size_t)r]); }
         if ((rc = validate_fused(d, FQ, bq))) return rc;
-        if ((rc = plan_items(d, FQ, bq, &sl.items, &sl.nb))) return rc;
+        // every other launch sweeps the frame groups backwards: what a half wrote last in one launch (still in the 256 MB
+        // Infinity Cache) is what the next launch reads first
+        if ((rc = plan_items(d, FQ, bq, d->sweep_reverse && (slot & 1), &sl.items, &sl.nb))) return rc;
         sl.n_roles = FQ.n_roles; sl.role_off = plan.h_roles.size();
         plan.h_roles.insert(plan.h_roles.end(), FQ.role, FQ.role + FQ.n_roles);
         plan.slots.push_back(sl);
@@ -1230,6 +1236,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE_CN")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave_cn = v; }
     if (const char *e = getenv("LUTLDPC_SKEW")) d->skew = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_REVERSE")) d->sweep_reverse = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_VALIDATE")) { d->validate = atoi(e) ? 1 : 0; if (d->validate) d->use_graph = 0; }
     int rc = compile_all(d.get());
     if (rc) return rc;

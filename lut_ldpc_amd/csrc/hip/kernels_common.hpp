@@ -113,11 +113,20 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
+// Cache policy of the row traffic (the aux immediate of the buffer instructions on gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// Every row is read once and written once per pass and the batch is far larger than L2 + Infinity Cache, so there is no
+// reuse to protect; the build-time defaults are what tools/ab_variants.sh measured fastest.
+#ifndef LUTLDPC_LD_AUX
+#define LUTLDPC_LD_AUX 0
+#endif
+#ifndef LUTLDPC_ST_AUX
+#define LUTLDPC_ST_AUX 0
+#endif
 __device__ __forceinline__ uint32_t ld_row(rsrc_t r, uint32_t row_off, uint32_t lane4) {
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane4, (int)row_off, 0);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane4, (int)row_off, LUTLDPC_LD_AUX);
 }
 __device__ __forceinline__ void st_row(rsrc_t r, uint32_t row_off, uint32_t lane4, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)lane4, (int)row_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)lane4, (int)row_off, LUTLDPC_ST_AUX);
 }
 
 // Entry of a software-pipelined loop whose first step was peeled: drain the vector-memory queue

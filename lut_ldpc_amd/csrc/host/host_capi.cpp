@@ -72,6 +72,8 @@ int lutldpc_codec_save(lutldpc_codec *c, const char *path) {
 
 int lutldpc_codec_destroy(lutldpc_codec *c) { delete c; return LUTLDPC_OK; }
 
+int lutldpc_codec_design_from_cache(lutldpc_codec *c) { return (c && c->C && c->C->design_came_from_cache()) ? 1 : 0; }
+
 int lutldpc_codec_design_luts(lutldpc_codec *c, const char *tree_method, int min_lut, double sigma2, int max_iters, const uint8_t *reuse_vec,
                               int Nq_Cha, const int32_t *Nq_Msg, int allow_degree_one, double *sigma_out) {
     return guarded([&] {

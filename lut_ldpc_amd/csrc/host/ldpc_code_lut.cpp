@@ -5,10 +5,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <unistd.h>
 
 namespace lut_ldpc {
 
@@ -213,16 +217,128 @@ void LDPC_Code_LUT::set_exit_conditions(int max_iters_in, bool syndr_check_each_
     if (dev && lutldpc_decoder_set_exit_conditions(dev, max_iters, psc, pisc) != LUTLDPC_OK) hip_fail("LDPC_Code_LUT::set_exit_conditions()");
 }
 
+// ------------------------------------------------------------------ design cache
+// A design is a pure function of (tree method [+ the tree file's text], degree distribution of the code, min_lut, sigma^2,
+// iterations, reuse pattern, alphabets, degree-1 extension): the 50-iteration density evolution of DVB-S2 takes ~25 s of
+// CPU every time ber_sim starts.  With LUTLDPC_DESIGN_CACHE=<directory> the result is kept there, keyed by a hash of all
+// those inputs, as text: the quantiser boundaries as hex floats (exact) and the trees in the reference's own serialisation
+// (operator<< of Array<Array<LUT_Tree>>, src/LUT_Tree.cpp:847-865) -- the same strings save_code writes into lut_codec.it.
+// Off unless the variable is set (the design parity tests always design).
+namespace {
+const char *kDesignCacheTag = "lutldpc-design-cache-1";
+
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } }
+    template <class T> void pod(const T &v) { bytes(&v, sizeof(T)); }
+    template <class T> void vec_(const std::vector<T> &v) { pod((uint64_t)v.size()); if (!v.empty()) bytes(v.data(), v.size() * sizeof(T)); }
+    void str(const std::string &s) { pod((uint64_t)s.size()); bytes(s.data(), s.size()); }
+};
+
+std::string design_cache_dir() {
+    const char *e = std::getenv("LUTLDPC_DESIGN_CACHE");
+    if (!e || !*e || std::string(e) == "0" || std::string(e) == "off") return std::string();
+    return e;
+}
+
+std::string design_key(const std::string &tree_method, const LDPC_Ensemble &ens, bool min_lut, double sigma2, int max_iters, const bvec &reuse_vec,
+                       int Nq_Cha, const ivec &Nq_Msg, bool allow_degree_one) {
+    Fnv f;
+    f.str(kDesignCacheTag); f.str(tree_method);
+    if (tree_method.rfind("filename=", 0) == 0) {            // the trees come from a file: its text is part of the key
+        std::ifstream in(tree_method.substr(9), std::ios::binary);
+        std::stringstream ss; ss << in.rdbuf(); f.str(ss.str());
+    }
+    f.vec_(ens.sget_degree_lam()); f.vec_(ens.sget_lam()); f.vec_(ens.sget_degree_rho()); f.vec_(ens.sget_rho());
+    f.pod((int)min_lut); f.pod(sigma2); f.pod(max_iters); f.vec_(reuse_vec); f.pod(Nq_Cha); f.vec_(Nq_Msg); f.pod((int)allow_degree_one);
+    char buf[32];
+    std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)f.h);
+    return buf;
+}
+
+void write_dvec(std::ostream &o, const char *name, const vec &v) {
+    o << name << ' ' << v.size();
+    char buf[64];
+    for (double x : v) { std::snprintf(buf, sizeof buf, " %a", x); o << buf; }
+    o << '\n';
+}
+bool read_dvec(std::istream &in, const char *name, vec &v) {
+    std::string tag; size_t n = 0;
+    if (!(in >> tag >> n) || tag != name || n > (1u << 20)) return false;
+    v.resize(n);
+    for (auto &x : v) { std::string t; if (!(in >> t)) return false; x = std::strtod(t.c_str(), nullptr); }
+    return true;
+}
+}  // namespace
+
+bool LDPC_Code_LUT::load_design(const std::string &path, const std::string &key, LUT_Tree_Array &var_luts, LUT_Tree_Array &chk_luts) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return false;
+    std::string tag, k;
+    if (!(in >> tag >> k) || tag != kDesignCacheTag || k != key) return false;
+    vec qc, qm;
+    ivec map;
+    if (!read_dvec(in, "qb_Cha", qc) || !read_dvec(in, "qb_Msg", qm)) return false;
+    { std::string t; size_t n = 0; if (!(in >> t >> n) || t != "map" || n > 4096) return false; map.resize(n); for (auto &x : map) if (!(in >> x)) return false; }
+    auto read_trees = [&](const char *name, LUT_Tree_Array &a) {
+        std::string t; size_t n = 0;
+        if (!(in >> t >> n) || t != name || n > (1u << 30)) return false;
+        in.get();                                            // the newline after the length
+        std::string txt(n, '\0');
+        if (n && !in.read(&txt[0], (std::streamsize)n)) return false;
+        std::istringstream is(txt);
+        if (n) is >> a;
+        return true;
+    };
+    try {
+        if (!read_trees("var_trees", var_luts) || !read_trees("chk_trees", chk_luts)) return false;
+    } catch (const std::exception &) { return false; }
+    std::string end;
+    if (!(in >> end) || end != "end") return false;         // a truncated file is not a design
+    qb_Cha = qc; qb_Msg = qm; Nq_Cha_2_Nq_Msg_map = map;
+    return true;
+}
+
+void LDPC_Code_LUT::store_design(const std::string &path, const std::string &key) const {
+    const std::string tmp = path + ".tmp" + std::to_string((long long)::getpid());
+    {
+        std::ofstream o(tmp, std::ios::binary);
+        if (!o) return;                                      // an unwritable cache directory only costs the next start its design
+        o << kDesignCacheTag << ' ' << key << '\n';
+        write_dvec(o, "qb_Cha", qb_Cha); write_dvec(o, "qb_Msg", qb_Msg);
+        o << "map " << Nq_Cha_2_Nq_Msg_map.size();
+        for (int x : Nq_Cha_2_Nq_Msg_map) o << ' ' << x;
+        o << '\n';
+        const std::string v = to_string(var_trees), c = minLUT ? std::string() : to_string(chk_trees);
+        o << "var_trees " << v.size() << '\n' << v << '\n' << "chk_trees " << c.size() << '\n' << c << '\n' << "end\n";
+        if (!o) { o.close(); std::remove(tmp.c_str()); return; }
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());      // atomic: ranks of one node share the directory
+}
+
 // src/LDPC_Code_LUT.cpp:699-746
 double LDPC_Code_LUT::design_luts(const std::string &tree_method, const LDPC_Ensemble &ens, bool min_lut, double sigma2, int max_iters_,
                                   const bvec &reuse_vec_, int Nq_Cha_, const ivec &Nq_Msg_, bool allow_degree_one) {
     minLUT = min_lut; max_iters = max_iters_; reuse_vec = reuse_vec_; Nq_Cha = Nq_Cha_; Nq_Msg = Nq_Msg_;
     if ((int)reuse_vec.size() != max_iters || (int)Nq_Msg.size() != max_iters)
         throw std::invalid_argument("LDPC_Code_LUT::design_luts(): reuse_vec / Nq_Msg must have max_iters entries");
+    const double sig = std::sqrt(sigma2);
     LUT_Tree_Array var_luts, chk_luts;
+    const std::string cache = design_cache_dir();
+    std::string key, path;
+    design_from_cache = false;
+    if (!cache.empty()) {
+        key = design_key(tree_method, ens, min_lut, sigma2, max_iters, reuse_vec, Nq_Cha, Nq_Msg, allow_degree_one);
+        path = cache + "/" + key + ".lutdesign";
+        if (load_design(path, key, var_luts, chk_luts)) {
+            set_trees(var_luts, chk_luts);
+            LUTs_defined = true;
+            design_from_cache = true;
+            return sig;
+        }
+    }
     get_lut_tree_templates(tree_method, ens, Nq_Msg, Nq_Cha, min_lut, var_luts, chk_luts, allow_degree_one);
     LDPC_DE_LUT de(ens, Nq_Cha, Nq_Msg, max_iters, var_luts, chk_luts, reuse_vec);
-    const double sig = std::sqrt(sigma2);
     de.get_quant_bound(sig, qb_Cha, qb_Msg);
     de.get_lut_trees(var_luts, chk_luts, sig);
     set_trees(var_luts, chk_luts);
@@ -232,6 +348,7 @@ double LDPC_Code_LUT::design_luts(const std::string &tree_method, const LDPC_Ens
     vec p_msg;
     (void)quant_mi_sym(p_msg, Nq_Cha_2_Nq_Msg_map, pmf_channel, Nq_Msg[0], true);
     LUTs_defined = true;
+    if (!path.empty()) store_design(path, key);
     return sig;
 }
 

@@ -68,6 +68,8 @@ public:
     // src/LDPC_Code_LUT.cpp:699-746; allow_degree_one: DESIGN.md "deviations"
     double design_luts(const std::string &tree_method, const LDPC_Ensemble &ens, bool min_lut, double sigma2, int max_iters,
                        const bvec &reuse_vec, int Nq_Cha, const ivec &Nq_Msg, bool allow_degree_one = false);
+    // design cache (LUTLDPC_DESIGN_CACHE=<dir>, see design_luts): did the last design_luts come from it?
+    bool design_came_from_cache() const { return design_from_cache; }
     void set_exit_conditions(int max_iters, bool syndr_check_each_iter = true, bool syndr_check_at_start = false);
 
     void encode(const bvec &input, bvec &output);
@@ -126,6 +128,9 @@ protected:
 
 private:
     void drop_device();
+    bool load_design(const std::string &path, const std::string &key, LUT_Tree_Array &var_luts, LUT_Tree_Array &chk_luts);
+    void store_design(const std::string &path, const std::string &key) const;
+    bool design_from_cache = false;
 
     bool H_defined = false, G_defined = false, LUTs_defined = false, minLUT = false;
     int nvar = 0, nchk = 0, nchk_lin_indep = 0;

@@ -193,6 +193,14 @@ int       or_codec_syndrome_ok(const or_codec *c, const unsigned char *bits);   
 void      or_codec_lut_decode_batch_u8(or_codec *c, const uint8_t *cha, const uint8_t *msg0, int B,
                                        uint8_t *out_bits, int32_t *out_iters);
 
+/* flat-table mode (or_flat.c): the same decode with the trees flattened into arrays and one frame per thread -- the CPU
+ * side-by-side leg (ii) of SURVEY.md 8(d).  The handle borrows the codec (exit conditions are read at decode time). */
+typedef struct or_flat or_flat;
+or_flat *or_flat_new(const or_codec *c);
+void     or_flat_free(or_flat *F);
+void     or_flat_decode_batch_u8(const or_flat *F, const uint8_t *cha, const uint8_t *msg0, int B,
+                                 uint8_t *out_bits, int32_t *out_iters, int n_threads);
+
 void or_free(void *p);
 
 #ifdef __cplusplus

@@ -53,6 +53,9 @@ def lib() -> C.CDLL:
             "or_codec_set_exit_conditions": (None, [vp, C.c_int, C.c_int, C.c_int]),
             "or_codec_lut_decode_batch_u8": (None, [vp, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int32)]),
             "or_codec_decode_llr": (C.c_int, [vp, dp, u8p, ip, ip]),
+            "or_flat_new": (vp, [vp]),
+            "or_flat_free": (None, [vp]),
+            "or_flat_decode_batch_u8": (None, [vp, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int32), C.c_int]),
             "or_codec_syndrome_ok": (C.c_int, [vp, u8p]),
             "or_api_codec_ninfo": (C.c_int, [vp]),
             "or_api_codec_rank": (C.c_int, [vp]),
@@ -228,6 +231,22 @@ class Codec:
         iters = np.zeros(B, np.int32)
         lib().or_codec_lut_decode_batch_u8(self._h, _u8p(cha), _u8p(msg0), B, _u8p(out),
                                            iters.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out, iters
+
+    def lut_decode_batch_flat(self, cha: np.ndarray, msg0: np.ndarray, threads: int = 0):
+        """Flat-table mode (or_flat.c): same results, trees flattened to arrays, one frame per thread (0 = all cores)."""
+        cha = np.ascontiguousarray(cha, np.uint8)
+        msg0 = np.ascontiguousarray(msg0, np.uint8)
+        B, N = cha.shape
+        assert N == self.code.nvar and msg0.shape == cha.shape
+        out = np.zeros((B, N), np.uint8)
+        iters = np.zeros(B, np.int32)
+        F = lib().or_flat_new(self._h)              # (re-flattened per call: the trees may have been replaced)
+        try:
+            lib().or_flat_decode_batch_u8(F, _u8p(cha), _u8p(msg0), B, _u8p(out), iters.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          int(threads) or (os.cpu_count() or 1))
+        finally:
+            lib().or_flat_free(F)
         return out, iters
 
     def tree_eval(self, kind: int, tree_set: int, cls: int, inputs, n_out: int) -> np.ndarray:

@@ -87,3 +87,28 @@ def test_codec_file_roundtrip(tmp_path):
 def test_de_threshold_readme_product():
     thr, it = L.de_threshold([2, 3, 9, 17], [0.138045, 0.401038, 0.026586, 0.434331], [8, 9], [0.323376, 0.676624])
     assert it == 20 and f"{thr:g}" == "0.929193"      # README.md:173-176
+
+
+def test_design_cache_roundtrip(tmp_path, monkeypatch):
+    """LUTLDPC_DESIGN_CACHE: the second design with equal inputs is read back (trees in the reference's text serialisation,
+    boundaries as hex floats) and is identical to a fresh design; other inputs miss; a damaged file is ignored."""
+    name = "reg36_n1000_mixed"
+    fresh = product_codec(name)
+    assert not fresh.design_from_cache
+    monkeypatch.setenv("LUTLDPC_DESIGN_CACHE", str(tmp_path))
+    a = product_codec(name)
+    assert not a.design_from_cache and len(list(tmp_path.glob("*.lutdesign"))) == 1
+    b = product_codec(name)
+    assert b.design_from_cache
+    assert b.var_trees_txt == fresh.var_trees_txt and (b.qb_cha == fresh.qb_cha).all() and (b.qb_msg == fresh.qb_msg).all()
+    assert (b.cha2msg_map == fresh.cha2msg_map).all()
+    c = product_codec("reg36_n1000_q3_chklut")            # other alphabets, CHKTREE designs
+    assert not c.design_from_cache and len(list(tmp_path.glob("*.lutdesign"))) == 2
+    d = product_codec("reg36_n1000_q3_chklut")
+    assert d.design_from_cache and d.chk_trees_txt == c.chk_trees_txt and d.var_trees_txt == c.var_trees_txt
+    for f in tmp_path.glob("*.lutdesign"):                 # truncated files are not designs
+        f.write_bytes(f.read_bytes()[:200])
+    e = product_codec(name)
+    assert not e.design_from_cache and e.var_trees_txt == fresh.var_trees_txt
+    for x in (fresh, a, b, c, d, e):
+        x.close()
