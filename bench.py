@@ -149,6 +149,25 @@ class PowerSampler:
                 "sclk_MHz": {"median": q(ck, 50), "p10": q(ck, 10), "p90": q(ck, 90)}}
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a job a
+    share of the host's cores, which os.cpu_count() does not show)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=9.0):
     """SURVEY 8(d), both CPU legs, on bounded samples of the same labels on this host's cores:
     (i) the oracle in FAITHFUL mode -- the reference's structure (per-output queue copy + recursive tree walk, one
@@ -170,7 +189,7 @@ def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=9.0):
     dt = time.perf_counter() - t0
     faithful = {"value": n / dt, "unit": "codewords/s", "cores": 1,
                 "sample": f"{n} frames, oracle faithful mode (per-output queue copy + recursive tree walk), {dt:.1f} s"}
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t0 = time.perf_counter()
     oc.lut_decode_batch_flat(cha[:cores], msg[:cores], threads=cores)
     t1 = (time.perf_counter() - t0) / 1.0

@@ -157,10 +157,14 @@ class BerSim:
         return buf.value.decode()
 
 
-def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False):
-    """LDPC_BER_Sim::run (src/LDPC_BER_Sim.cpp:121-155) + save(), sharded over comm."""
+def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False, batch_override=None):
+    """LDPC_BER_Sim::run (src/LDPC_BER_Sim.cpp:121-155) + save(), sharded over comm.
+
+    batch_override(sim, snr_index, frame0, B) -> [B, 4] replaces the device batch (sampler + decode + counting); the CPU
+    tests of the multi-rank path pass the oracle there, with the simulation object created host-only (device = -1)."""
     comm = comm or Comm()
-    sim = BerSim(params, base_dir, seed, custom_name, device)
+    sim = BerSim(params, base_dir, seed, custom_name, -1 if batch_override else device)
+    batch = (lambda i, f, b: batch_override(sim, i, f, b)) if batch_override else sim.batch
     t0 = time.perf_counter()
     points = []
     stop_sweep = False
@@ -168,7 +172,7 @@ def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, d
         if stop_sweep:
             c = np.zeros(5, np.int64)                              # remaining points are padded, :142-149
         else:
-            c = sim_snr_point_sharded(lambda f, b: sim.batch(idx, f, b), sim.nframes, sim.nfers, sim.ninfo, comm, sim.batch_frames)
+            c = sim_snr_point_sharded(lambda f, b: batch(idx, f, b), sim.nframes, sim.nfers, sim.ninfo, comm, sim.batch_frames)
             ber = c[3] / c[1] if c[1] else 0.0
             fer = c[2] / c[0] if c[0] else 0.0
             if comm.rank == 0 and not quiet:

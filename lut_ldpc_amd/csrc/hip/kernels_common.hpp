@@ -115,12 +115,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
 }
 // Cache policy of the row traffic (the aux immediate of the buffer instructions on gfx950: 1 = sc0, 2 = nt, 16 = sc1).
 // Every row is read once and written once per pass and the batch is far larger than L2 + Infinity Cache, so there is no
-// reuse to protect; the build-time defaults are what tools/ab_variants.sh measured fastest.
+// reuse to protect: non-temporal loads AND stores.  Measured with tools/ab_variants.sh (DVB-S2, 16384 frames, six
+// interleaved processes per variant on one box, profiles/r02_ab_cache_policy.txt): nt/nt +3.7 % over the default
+// policy, nt loads alone +0.3 %, nt stores alone +0.5 %, sc1 (write-through) stores +2.8 %.
 #ifndef LUTLDPC_LD_AUX
-#define LUTLDPC_LD_AUX 0
+#define LUTLDPC_LD_AUX 2
 #endif
 #ifndef LUTLDPC_ST_AUX
-#define LUTLDPC_ST_AUX 0
+#define LUTLDPC_ST_AUX 2
 #endif
 __device__ __forceinline__ uint32_t ld_row(rsrc_t r, uint32_t row_off, uint32_t lane4) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane4, (int)row_off, LUTLDPC_LD_AUX);

@@ -132,3 +132,34 @@ def test_python_driver_equals_cpp_driver(tmp_path):
     assert n == len(pts)
     assert (np.array(cnt[:n * 5]).reshape(n, 5) == np.array([c for _, c in pts])).all()
     assert path and itload(path)["sim_SNRdB"][1] == 0.5
+
+
+def test_config4_sweep_on_one_gpu_at_reduced_nframes(tmp_path):
+    """BASELINE config 4 (data/params/ber.ini.dvbs2_sweep) through lut_ldpc_amd.ber_sim.run on one GPU, Nframes reduced:
+    the sweep stops and pads like the reference, and frames of a mid-SNR point equal the oracle's on the same Philox frames."""
+    import re
+    from lut_ldpc_amd import ber_sim
+    base = tmp_path / "base"
+    (base / "codes").mkdir(parents=True)
+    shutil.copy(CODES / "rate0.50_irreg_dvbs2_N64800.alist", base / "codes")
+    txt = (ROOT / "data" / "params" / "ber.ini.dvbs2_sweep").read_text()
+    params = tmp_path / "ber.ini.dvbs2_sweep"
+    params.write_text(re.sub(r"Nframes\s*=\s*1e6", "Nframes  = 3000", txt))
+    pts, path = ber_sim.run(params, base, seed=5, quiet=True)
+    cnt = np.array([c for _, c in pts])
+    assert cnt[0][0] == 21 and cnt[0][2] == 21                     # 0 dB: stops after Nfers + 1 frame errors (:289)
+    stop = int(np.flatnonzero(cnt[:, 2] == 0)[0])
+    assert cnt[stop][0] == 3000 and (cnt[stop + 1:] == 0).all()    # first error-free point ends the sweep (:307), the rest is padded
+    assert itload(path)["sim_Nframes"].tolist() == cnt[:, 0].tolist()
+    # the oracle on 24 frames of the point before the stop (a mix of early exits and frames that run all 50 iterations)
+    sim = ber_sim.BerSim(params, base, 5, "", 0)
+    idx = stop - 1
+    got = sim.batch(idx, 100, 24)
+    sim.close()
+    cd = oracle_codec("dvbs2_q4")
+    cd.set_exit_conditions(50, True, True)
+    cha, msg, unc = cd.sample_labels(pts[idx][0], 0.5, 5, idx, 100, 24)
+    bits, it = cd.lut_decode_batch_flat(cha, msg)
+    be = bits[:, :32400].sum(1)
+    want = np.stack([it, be > 0, be, unc], 1).astype(np.int32)
+    assert (got == want).all(), np.argwhere(got != want)[:5]

@@ -1,13 +1,11 @@
 #!/bin/bash
 # A/B of library variants built by tools/build_variant.sh, interleaved (default, variants..., default, variants...) so that
 # the run-to-run levels of a box show up as spread within each variant.  Usage: tools/ab_variants.sh <rounds> <variant>...
-# Output: gpurun_out/ab_variants.txt (value k cw/s, fused launch ms per run) and gpurun_out/ab_clocks.txt (clock / power samples)
+# Output: gpurun_out/ab_variants.txt (value k cw/s, fused launch ms per run), then medians per variant
 rounds=${1:-2}; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out; mkdir -p "$out"
 : > "$out/ab_variants.txt"
-( while true; do date +%s.%N; rocm-smi --showclocks --showpower --showuse 2>/dev/null | grep -E "sclk|mclk|fclk|socclk|Power|busy" ; sleep 3; done ) > "$out/ab_clocks.txt" 2>&1 &
-sampler=$!
 for r in $(seq 1 "$rounds"); do
   for v in default "$@"; do
     # a variant is  <build>[:ENV=VAL[,ENV=VAL...]]  -- <build> = default or a directory of lut_ldpc_amd/lib_variants/
@@ -23,4 +21,12 @@ print('$v', 'round $r', 'k_cw_s %.1f' % (d['value']/1e3), 'fused_ms %.4f' % d['r
     tail -1 "$out/ab_variants.txt"
   done
 done
-kill $sampler
+python3 - "$out/ab_variants.txt" <<'PY'
+import sys, collections, statistics
+v = collections.defaultdict(list)
+for ln in open(sys.argv[1]):
+    p = ln.split()
+    if "k_cw_s" in p:
+        v[p[0]].append(float(p[p.index("k_cw_s") + 1]))
+print("---- medians (k cw/s): " + "  ".join(f"{k}: {statistics.median(x):.1f} [{min(x):.1f}..{max(x):.1f}] n={len(x)}" for k, x in v.items()))
+PY

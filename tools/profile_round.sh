@@ -2,19 +2,26 @@
 # Collects the artifacts behind the roofline numbers of one round (run on the GPU box through gpurun):
 #   <out>/bench.json                 the default bench line
 #   <out>/kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command
-#   <out>/pmc_fetch.csv, pmc_write.csv   FETCH_SIZE / WRITE_SIZE, separate --pmc passes (kernel trace only)
-# Usage: tools/profile_round.sh <out-dir>
+#   <out>/pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv   HBM traffic, separate --pmc passes (kernel trace only)
+#   <out>/pmc_sq_a.csv, pmc_sq_b.csv what limits the fused kernel on the chip (VALU issue, LDS, waits)
+# Usage: tools/profile_round.sh <out-dir> [extra bench args]
 set -e
-OUT=$1
+OUT=$1; shift
 mkdir -p "$OUT"
 R=$GRAFT_REPO_ROOT
-python3 "$R/bench.py" > "$R/$OUT/bench.json" 2> "$R/$OUT/bench.err"
+python3 "$R/bench.py" "$@" > "$R/$OUT/bench.json" 2> "$R/$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline --frame-loop-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline --frame-loop-steps 0 --reps 0 "$@" > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/trace.err"
 find "$R/$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$R/$OUT/kernel_stats.csv" \;
-for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/$OUT/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --frame-loop-steps 0 --no-kernel-events > /dev/null 2> "$R/$OUT/pmc_$c.err"
-    find "$R/$OUT/pmc_$c" -name "*counter_collection.csv" -exec cp {} "$R/$OUT/pmc_$c.csv" \;
-done
-rm -rf "$R/$OUT/trace" "$R/$OUT/pmc_FETCH_SIZE" "$R/$OUT/pmc_WRITE_SIZE"
+pmc() {   # name, counters...
+    local name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$OUT/pmc_$name" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --frame-loop-steps 0 --no-kernel-events --reps 0 $BENCH_ARGS > /dev/null 2> "$R/$OUT/pmc_$name.err"
+    find "$R/$OUT/pmc_$name" -name "*counter_collection.csv" -exec cp {} "$R/$OUT/pmc_$name.csv" \;
+    rm -rf "$R/$OUT/pmc_$name"
+}
+pmc FETCH_SIZE FETCH_SIZE
+pmc WRITE_SIZE WRITE_SIZE
+pmc sq_a GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY
+pmc sq_b GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM
+rm -rf "$R/$OUT/trace"
 ls -la "$R/$OUT"
