@@ -366,6 +366,18 @@ def main():
         if t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
             traffic = t.get("fused_pass_hbm_bytes_per_launch" if fu["launches"] else "vn_pass_hbm_bytes_per_pass")
             break
+    # what limits the dominant kernel on the chip besides HBM (SQ counters collected by tools/profile_round.sh in their own
+    # rocprofv3 --pmc passes, summarised by tools/pmc_limiter.py and committed under profiles/; same validity rule)
+    limiter = None
+    for f in sorted((ROOT / "profiles").glob("*pmc_limiter*.json"), reverse=True):
+        t = json.loads(f.read_text())
+        if t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode:
+            limiter = {"valu_busy": t["valu_busy"], "lds_busy": t["lds_busy"],
+                       "lds_bank_conflict_share_of_lds_cycles": t["lds_bank_conflict_share_of_lds_cycles"],
+                       "hbm_share_of_achievable_6p3TBps": None, "source": f.name,
+                       "note": "shares of the launch during which the vector ALUs issue / the LDS is busy (rocprofv3 --pmc); "
+                               "the kernel is co-limited: no single unit is saturated, all three are above 70 %"}
+            break
     if fu["launches"]:
         # skewed two-half pipeline: one decode = 2*I launches of pass_fused_kernel which together carry the
         # I check passes and I-1 variable passes of every frame (first/last launch work on one half only)
@@ -381,6 +393,9 @@ def main():
                 "algorithmic_bytes_per_launch": fu_bytes, "avg_launch_ms": fu_ms, "launches": fu["launches"],
                 "bytes_not_moved_thanks_to_chain_fusion_per_launch": saved,
                 "achieved_after_fusion_GBps": (fu_bytes - saved) / (fu_ms * 1e-3) / 1e9}
+        if limiter is not None:
+            limiter["hbm_share_of_achievable_6p3TBps"] = ((traffic if traffic else fu_bytes - saved) / (fu_ms * 1e-3) / 1e9) / 6300.0
+            roof["limiter"] = limiter
     else:
         roof = {"bound": "hbm", "kernel": "vn_pass", "achieved": vn_bytes / (vn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": vn_bytes / (vn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,

@@ -17,6 +17,7 @@ namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -128,7 +129,8 @@ struct lutldpc_decoder {
     // compaction of the surviving frames (kernels_compact.hpp): as-shipped mode, skewed pipeline
     // (off by default: measured on MI355X it does not pay -- DVB-S2 frames finish too late (41.7 of 50 iterations on
     // average), (3,6) frames finish so close together that whole groups fall idle by themselves; LUTLDPC_COMPACT=1)
-    int use_compact = 0, compact_first = 6, compact_every = 4;
+    int use_compact = 0, compact_first = 4, compact_every = 0;      // every: 0 = derived from the duration of an iteration
+    float compact_margin = 1.25f;                                   // LUTLDPC_COMPACT_MARGIN (0: permute whenever a group falls idle)
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
@@ -138,6 +140,12 @@ struct lutldpc_decoder {
     // LUTLDPC_VALIDATE=1 (debug): every role of a fused launch is checked against the allocation sizes before the launch and
     // the stream is synchronised after it, so that a device fault is attributed to ONE launch (no graph replay then)
     int validate = 0;
+    // as-shipped mode: the decided bits of early-terminated frames are recovered once, at the end, from their frozen messages
+    // (hard_from_frozen_kernel) instead of being stored by every variable pass.  Needs the min-sum check update and one
+    // message alphabet; LUTLDPC_LATE_HARD=0 restores the stores.
+    int late_hard = 1;
+    DevBuf<uint8_t> d_chain_internal;      // 1 = variable node updated inside the check pass (build_fast_index)
+    std::vector<uint8_t> chain_internal;
     int sweep_reverse = 0;      // LUTLDPC_REVERSE: alternate the sweep direction over the frame groups between launches
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
@@ -323,6 +331,7 @@ void build_fast_index(lutldpc_decoder *d) {
     }
     d->n_chain_nodes = 0;
     for (char x : internal) d->n_chain_nodes += x;
+    d->chain_internal.assign(internal.begin(), internal.end());
 }
 
 // Every entry of the dense index tables the specialised kernels read with scalar loads must address a row that exists:
@@ -516,6 +525,7 @@ int upload_static(lutldpc_decoder *d) {
     HIP_TRY(d->d_vn_list.upload(d->vn_list));
     HIP_TRY(d->d_cn_list.upload(d->cn_list));
     HIP_TRY(d->d_fast_idx.upload(d->fast_idx));
+    HIP_TRY(d->d_chain_internal.upload(d->chain_internal));
     HIP_TRY(d->d_ops.upload(d->all_ops));
     {   // pad the table blob so that dword staging never reads past the end
         std::vector<uint8_t> t = d->all_tables;
@@ -722,6 +732,23 @@ bool skew_eligible(const lutldpc_decoder *d) {
     return true;
 }
 
+// Are the decided bits of early-terminated frames recovered at the end (hard_from_frozen_kernel) instead of being stored by
+// every variable pass?  Min-sum checks, one message alphabet, no compaction (it drops the messages of finished frames), and
+// -- in the skewed pipeline -- chain fusion on in every iteration or in none (the nodes it updates get their bits from the
+// check pass).  `chain_skip`: those nodes are skipped by the recovery.
+bool chain_active(const lutldpc_decoder *d, int set);
+bool late_hard_active(const lutldpc_decoder *d, bool skewed, bool *chain_skip) {
+    if (chain_skip) *chain_skip = false;
+    if (!d->late_hard || !d->psc || !d->min_lut || d->use_compact) return false;
+    for (int i = 1; i < d->max_iters; i++) if (d->Nq_Msg[(size_t)i] != d->Nq_Msg[0]) return false;
+    if (!skewed) return true;
+    int on = 0, off = 0;
+    for (int ii = 0; ii + 1 < d->max_iters; ii++) (chain_active(d, d->iter_set[(size_t)ii]) ? on : off)++;
+    if (on && off) return false;
+    if (chain_skip) *chain_skip = on > 0;
+    return true;
+}
+
 // chain fusion applies to a check pass that is followed by a variable pass (not the last iteration), on the first
 // degree bucket, when the degree-2 class has the compile-time kernel (its root table is staged)
 bool chain_active(const lutldpc_decoder *d, int set) {
@@ -877,17 +904,23 @@ int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan,
     return LUTLDPC_OK;
 }
 
-// kernels_compact.hpp: permute the slots of one half (active frames first) right after its exit test of iteration ii
+// kernels_compact.hpp: a check point of one half right after its exit test of iteration ii -- the plan kernel decides on the
+// device whether permuting the slots (active frames first) pays; if not, the row kernels return at once
+constexpr unsigned kPermuteBlocks = 1024;
+// LDS of permute_rows_kernel: the row tiles of four waves + the 16-bit descriptors of every label of the half
+size_t permute_lds_bytes(const lutldpc_decoder *d, int GH) { return (size_t)4 * GH * 64 * sizeof(uint32_t) + (size_t)GH * d->tile() * sizeof(uint16_t); }
+bool compaction_fits(const lutldpc_decoder *d, int GH) { return GH <= kPermuteMaxGroups && permute_lds_bytes(d, GH) <= 64 * 1024; }
 int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     Timed t(d, LUTLDPC_K_LAYOUT);
     const int T = d->tile(), s0 = h.g0 * T, n = h.G * T;
     if (n <= 0) return LUTLDPC_OK;
     uint8_t *pending = d->d_vfail.p + (size_t)((ii + 1) & 1) * kVfailSlots * d->Bcap;      // flags already raised for the next test
     hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n, T,
-                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, d->d_ctl.p + 4 * hf);
-    const size_t lds = (size_t)4 * h.G * 64 * sizeof(uint32_t);
+                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, d->d_ctl.p + 4 * hf, d->max_iters - 1 - ii, d->compact_margin);
+    const size_t lds = permute_lds_bytes(d, h.G);
     auto rows = [&](uint8_t *buf, int n_rows, int gather) {
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), lds, d->stream, buf, n_rows, n_rows, h.g0, h.G,
+        const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((n_rows + 3) / 4));
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(blocks), dim3(256), lds, d->stream, buf, n_rows, n_rows, h.g0, h.G,
                                             d->d_perm.p, d->d_ctl.p + 4 * hf, gather));
     };
     rows(d->d_msgs.p, d->E, 1);
@@ -902,8 +935,8 @@ int launch_uncompaction(lutldpc_decoder *d, const HalfRange (&half)[2], int Bpad
     hipLaunchKernelGGL(invert_map_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, d->d_slot_of.p, 0, Bpad);
     for (int hf = 0; hf < 2; hf++) {
         if (half[hf].G <= 0) continue;
-        const size_t lds = (size_t)4 * half[hf].G * 64 * sizeof(uint32_t);
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3((unsigned)((d->nvar + 3) / 4)), dim3(256), lds, d->stream, d->d_hard.p, d->nvar, d->nvar,
+        const size_t lds = permute_lds_bytes(d, half[hf].G);
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(std::min<unsigned>(kPermuteBlocks, (unsigned)((d->nvar + 3) / 4))), dim3(256), lds, d->stream, d->d_hard.p, d->nvar, d->nvar,
                                             half[hf].g0, half[hf].G, d->d_slot_of.p, (const int32_t *)nullptr, 0));
     }
     hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_iters.p, d->d_slot_of.p, d->d_iters_tmp.p, 0, Bpad);
@@ -933,7 +966,7 @@ int build_skew_plan(lutldpc_decoder *d, int G, lutldpc_decoder::SkewPlan &plan) 
                 add_cn_roles(d, FP, blocks, half[hf], ii, check);
                 if (check) { sl.state_half = hf; sl.state_ii = ii; }
             } else {                                  // VN(ii)
-                add_vn_roles(d, FP, blocks, half[hf], ii, psc, psc);
+                add_vn_roles(d, FP, blocks, half[hf], ii, psc, (psc && !late_hard_active(d, true, nullptr)) ? 1 : 0);
             }
         }
         // roles without work (an empty half when G == 1 never gets here; a degree class emptied by chain fusion does)
@@ -965,7 +998,11 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
         pp = std::move(np);
     }
     const lutldpc_decoder::SkewPlan &plan = *pp;
-    const bool compact = psc && d->use_compact;
+    // compaction of the surviving frames: check points every `every` iterations (a check point costs four short launches
+    // per half: keep that below a few per cent of an iteration, whose duration is estimated from its row traffic)
+    const bool compact = psc && d->use_compact && compaction_fits(d, half[0].G);
+    const double est_iter_us = (4.0 * d->E + 3.0 * d->nvar) * kRowBytes * G / 5.5e6;
+    const int every = d->compact_every > 0 ? d->compact_every : std::max(2, std::min(16, (int)std::ceil(60.0 / std::max(est_iter_us, 1.0))));
     if (compact) {
         Timed t(d, LUTLDPC_K_LAYOUT);
         hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
@@ -976,7 +1013,7 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
         if (sl.state_half >= 0) {                     // :327-329 returns (ii-1)+1
             const int f0 = half[sl.state_half].g0 * d->tile(), f1 = f0 + half[sl.state_half].G * d->tile();
             if ((rc = launch_state(d, B, Bpad, 2, sl.state_ii, f0, f1, sl.state_ii & 1))) return rc;
-            if (compact && sl.state_ii >= d->compact_first && sl.state_ii < I - 1 && (sl.state_ii - d->compact_first) % d->compact_every == 0 &&
+            if (compact && sl.state_ii >= d->compact_first && sl.state_ii < I - 2 && (sl.state_ii - d->compact_first) % every == 0 &&
                 (rc = launch_compaction(d, half[sl.state_half], sl.state_half, sl.state_ii))) return rc;
         }
     }
@@ -1020,8 +1057,18 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
         if (ii != I - 1) {
             const int nz_out = d->Nq_Msg[(size_t)(ii + 1)] / 2;
-            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], d->var_jit.empty() ? nullptr : &d->var_jit[(size_t)set], G, nz_out, d->psc ? 1 : 0, d->psc ? 1 : 0, LUTLDPC_K_VN_PASS);
+            rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], d->var_jit.empty() ? nullptr : &d->var_jit[(size_t)set], G, nz_out, d->psc ? 1 : 0,
+                                          (d->psc && !late_hard_active(d, false, nullptr)) ? 1 : 0, LUTLDPC_K_VN_PASS);
             if (rc) return rc;
+        }
+    }
+    {   // decided bits of the frames that left through the exit test, from their frozen messages (see late_hard_active)
+        bool chain_skip = false;
+        if (late_hard_active(d, skewed, &chain_skip)) {
+            Timed t(d, LUTLDPC_K_LAYOUT);
+            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
+                                                reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, N, E, d->Nq_Msg[0] / 2));
+            LAUNCH_CHECK();
         }
     }
     // :340-349
@@ -1029,7 +1076,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     const int fsel = skewed ? (I & 1) : 0;            // the flag buffer no pass of the skewed pipeline has written since its last test
     if ((rc = launch_syndrome(d, G, fsel))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I, 0, -1, fsel))) return rc;
-    if (skewed && d->psc && d->use_compact) {
+    if (skewed && d->psc && d->use_compact && compaction_fits(d, (G + 1) / 2)) {
         const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
         if ((rc = launch_uncompaction(d, half, Bpad))) return rc;
     }
@@ -1231,11 +1278,13 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT_EVERY")) { int v = atoi(e); if (v >= 1) d->compact_every = v; }
+    if (const char *e = getenv("LUTLDPC_COMPACT_MARGIN")) { double v = atof(e); if (v >= 0 && v < 100) d->compact_margin = (float)v; }
     if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE_CN")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave_cn = v; }
     if (const char *e = getenv("LUTLDPC_SKEW")) d->skew = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_LATE_HARD")) d->late_hard = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_REVERSE")) d->sweep_reverse = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_VALIDATE")) { d->validate = atoi(e) ? 1 : 0; if (d->validate) d->use_graph = 0; }
     int rc = compile_all(d.get());
@@ -1261,7 +1310,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (auto &e : d->ev_live) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : d->ev_pool) (void)hipEventDestroy(e);
-        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release();
+        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release(); d->d_chain_internal.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();

@@ -11,24 +11,32 @@
 //
 // One permutation = compact_plan_kernel (one block per half: prefix sum, small per-slot arrays) +
 // permute_rows_kernel over the E message rows, the N channel rows and the N decided-bit rows.
+//
+// Whether a permutation pays is decided ON THE DEVICE at every check point (the launch sequence is a fixed hipGraph): it
+// moves  (live + new) groups of message / channel rows  and all decided-bit rows, about  0.35 (live + new) + 0.15 GH
+// iteration-equivalents of row traffic, and saves  (live - new) groups x remaining iterations.  compact_plan_kernel
+// permutes only when the saving exceeds 1.25 x that cost; otherwise the row kernels of the check point return at once
+// (a few microseconds per check point).
 #pragma once
 #include "kernels_common.hpp"
 
 namespace lutldpc {
 
-// decode start: frame_of = identity, ctl[half] = {n_active, skip, live groups, -}
+// decode start: frame_of = identity, ctl[half] = {n_active, skip, live groups, live groups before the last permutation}
 __global__ __launch_bounds__(256) void compact_init_kernel(int32_t *__restrict__ frame_of, int n, int32_t *__restrict__ ctl, int gh0, int gh1) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) frame_of[i] = i;
-    if (i == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = gh0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 1; ctl[6] = gh1; ctl[7] = 0; }
+    if (i == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = gh0; ctl[3] = gh0; ctl[4] = 0; ctl[5] = 1; ctl[6] = gh1; ctl[7] = gh1; }
 }
 
 // Slots [s0, s0 + n): perm[new] = old (absolute slot numbers), active frames first.  Applies the permutation to
 // state / iters / frame_of and to the pending flag buffer (its kVfailSlots copies are ORed into copy 0).
-// tmp: 3 * n int32 of scratch.  ctl = {n_active, skip, live groups} of this half.
+// tmp: 3 * n int32 of scratch.  ctl = {n_active, skip, live groups, live groups before this permutation} of this half.
+// iters_left: message-passing iterations still to run after this check point; margin: permute when saving >= margin x cost
+// (1.25; 0 = whenever a group falls idle, for the tests).
 __global__ __launch_bounds__(1024) void compact_plan_kernel(uint8_t *__restrict__ state, int32_t *__restrict__ iters, int32_t *__restrict__ frame_of,
                                                              uint8_t *__restrict__ vfail_pending, int vfail_stride, int s0, int n, int tile_frames,
-                                                             int32_t *__restrict__ perm, int32_t *__restrict__ tmp, int32_t *__restrict__ ctl)
+                                                             int32_t *__restrict__ perm, int32_t *__restrict__ tmp, int32_t *__restrict__ ctl, int iters_left, float margin)
 {
     __shared__ int wsum[16];
     __shared__ int base_act, base_rest, total_act;
@@ -43,10 +51,13 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(uint8_t *__restrict_
         int s = 0;
         for (int k = 0; k < 16; k++) s += wsum[k];
         total_act = s; base_act = 0; base_rest = s;
-        // ctl = {n_active, skip, live groups}: permute only when at least one more group falls idle
-        const int gnew = (s + tile_frames - 1) / tile_frames;
+        // permute only when the groups that fall idle save more row traffic over the remaining iterations than moving
+        // the survivors costs (see the header of this file)
+        const int gnew = (s + tile_frames - 1) / tile_frames, live = ctl[2], gh = n / tile_frames;
+        const float gain = (float)(live - gnew) * (float)iters_left;
+        const float cost = 0.35f * (float)(live + gnew) + 0.15f * (float)gh;
         ctl[0] = s;
-        if (gnew < ctl[2]) { ctl[1] = 0; ctl[2] = gnew; } else ctl[1] = 1;
+        if (gnew < live && gain >= margin * cost) { ctl[1] = 0; ctl[3] = live; ctl[2] = gnew; } else ctl[1] = 1;
         total_act = ctl[1];                     // (re-used as the block-wide skip flag)
     }
     __syncthreads();
@@ -106,38 +117,57 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t *__restri
 
 // rows[g][r][256 B], groups g0 .. g0+GH-1 (one half): row r of every group is rebuilt as
 //     new slot s  <-  old slot perm[s]        (slots relative to the half: perm values are absolute, s0 = g0 * tile)
-// for the first `limit` new slots only (limit = n_active[0] when gather_active, else all): one wave per row, the GH
-// old dwords of a lane go through a wave-private LDS tile, every new dword is assembled from F label picks.
+// for the first `limit` new slots only (limit = n_active[0] when gather_active, else all).
+// The permutation is the same for every row, so a block first turns it into DESCRIPTORS in LDS -- for every label of
+// every new dword {dword index in the wave's tile of old rows, bit offset}, 16 bits -- and then streams rows: a wave loads
+// the `gold` old dwords of its lane (eight loads in flight), parks them in its LDS tile, and assembles every new dword
+// from F picks {LDS read, shift, mask, merge}.  Memory-bound: (gold + gnew) rows of traffic per row index.
+// LDS: [4 waves][GH][64] dwords + [gnew][64][F] descriptors (GH <= 32: dword index < 2048 = 11 bits, bit offset 5 bits).
+constexpr int kPermuteMaxGroups = 32;
 template <int PACK>
 __global__ __launch_bounds__(256) void permute_rows_kernel(uint8_t *__restrict__ rows, int n_rows, int rows_per_group, int g0, int GH,
                                                            const int32_t *__restrict__ perm, const int32_t *__restrict__ ctl, int gather_active)
 {
     constexpr int F = 4 * PACK, BITS = 8 / PACK, T = kRowBytes * PACK;
-    extern __shared__ uint32_t tile[];                        // [4 waves][GH][64]
+    extern __shared__ uint32_t tile[];                        // [4 waves][GH][64] | descriptors
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + w;
-    if (r >= n_rows) return;
+    if (ctl && ctl[1]) return;                                 // the plan kernel found nothing to gain (block-uniform)
     uint32_t *my = tile + (size_t)w * GH * 64;
+    uint16_t *desc = reinterpret_cast<uint16_t *>(tile + (size_t)4 * GH * 64);
     const int s0 = g0 * T;
-    if (ctl && ctl[1]) return;                                 // the plan kernel found nothing to gain
     const int limit = gather_active ? ctl[0] : GH * T;
     const int gnew = (limit + T - 1) / T;                      // groups that receive frames
+    const int gold = (ctl && gather_active) ? ctl[3] : GH;     // groups that still held active frames before this permutation
     if (gnew == 0) return;
-    for (int g = 0; g < GH; g++)
-        my[g * 64 + lane] = *reinterpret_cast<const uint32_t *>(rows + ((size_t)(g0 + g) * rows_per_group + r) * kRowBytes + lane * 4);
-    // (wave-private tile: no barrier needed, the LDS queue is in order within a wave)
-    for (int g = 0; g < gnew; g++) {
-        uint32_t out = 0;
-        const int32_t *pp = perm + s0 + g * T + lane * F;
+    for (int i = threadIdx.x; i < gnew * T; i += 256) {        // new slot i of the half = (group i / T, lane (i % T) / F, label i % F)
+        const int o = perm[s0 + i] - s0;                       // old slot within the half
+        const int go = o / T, fo = o - go * T, lo = fo / F, jo = fo - lo * F;
+        // label jo of a lane sits at half jo / 4, byte jo % 4 (kernels_common.hpp): bit offset 8 * (jo % 4) + BITS * (jo / 4)
+        desc[i] = go < gold ? (uint16_t)((go * 64 + lo) | ((8 * (jo & 3) + BITS * (jo >> 2)) << 11)) : (uint16_t)0xFFFFu;
+    }
+    __syncthreads();
+    // a fixed, small grid walks the rows (an empty check point must cost microseconds, not one block per row)
+    for (int r = blockIdx.x * 4 + w; r < n_rows; r += gridDim.x * 4) {
+        for (int gb = 0; gb < gold; gb += 8) {                 // eight row loads in flight per lane
+            uint32_t v[8];
 #pragma unroll
-        for (int j = 0; j < F; j++) {
-            const int o = pp[j] - s0;                          // old slot within the half
-            const int go = o / T, fo = o - go * T, lo = fo / F, jo = fo - lo * F;
-            // frame jo of a lane sits at half jo / 4, byte jo % 4 (kernels_common.hpp): bit offset 8 * (jo % 4) + BITS * (jo / 4)
-            const uint32_t v = (my[go * 64 + lo] >> (8 * (jo & 3) + BITS * (jo >> 2))) & ((1u << BITS) - 1u);
-            out |= v << (8 * (j & 3) + BITS * (j >> 2));
+            for (int k = 0; k < 8; k++)
+                v[k] = gb + k < gold ? *reinterpret_cast<const uint32_t *>(rows + ((size_t)(g0 + gb + k) * rows_per_group + r) * kRowBytes + lane * 4) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (gb + k < gold) my[(gb + k) * 64 + lane] = v[k];
         }
-        *reinterpret_cast<uint32_t *>(rows + ((size_t)(g0 + g) * rows_per_group + r) * kRowBytes + lane * 4) = out;
+        // (wave-private tile: no barrier needed, the LDS queue is in order within a wave)
+        for (int g = 0; g < gnew; g++) {
+            uint32_t out = 0;
+            const uint16_t *dd = desc + ((size_t)g * 64 + lane) * F;
+#pragma unroll
+            for (int j = 0; j < F; j++) {
+                const uint32_t de = dd[j];
+                const uint32_t v = de != 0xFFFFu ? (my[de & 0x7FFu] >> (de >> 11)) & ((1u << BITS) - 1u) : 0u;
+                out |= v << (8 * (j & 3) + BITS * (j >> 2));
+            }
+            *reinterpret_cast<uint32_t *>(rows + ((size_t)(g0 + g) * rows_per_group + r) * kRowBytes + lane * 4) = out;
+        }
     }
 }
 

@@ -401,6 +401,33 @@ __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__
     reinterpret_cast<uint32_t *>(hard)[i] = pack_halves<PACK>(r);
 }
 
+// Decided bits of the frames that left through the exit test (ST_DONE_PSC), recovered ONCE at the end of the decode from
+// their frozen messages instead of being stored by every variable pass.  The reference returns the unanimous signs of the
+// variable-to-check messages of iteration ii (src/LDPC_Code_LUT.cpp:327-329,437-452); here the frame is frozen one check
+// pass later, with the check-to-variable messages of iteration ii+1 in place.  For a frame that PASSED the test every
+// check is satisfied, and the min-sum output on an edge then carries the sign of its own input on that edge
+// (chk_update_minsum, :355-402: sign_msg = sign_prod ^ own sign, sign_prod = 0), i.e. the unanimous sign of the variable
+// node: bit v = (label on the node's first edge < nz).  Exact for min-sum check updates with one message alphabet; the
+// nodes updated inside the check pass (chain fusion, `skip`) keep the bits that pass stored for them.
+template <int PACK>
+__global__ __launch_bounds__(256) void hard_from_frozen_kernel(const uint8_t *__restrict__ msgs, uint8_t *__restrict__ hard,
+                                                               const uint32_t *__restrict__ state_w, const int32_t *__restrict__ vn_ptr,
+                                                               const uint8_t *__restrict__ skip, int N, int E, int nz)
+{
+    const int lane = threadIdx.x & 63, g = blockIdx.y;
+    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (v >= N || (skip && skip[v])) return;
+    uint32_t m[PACK], any = 0;
+#pragma unroll
+    for (int h = 0; h < PACK; h++) { m[h] = swar_zero_mask(state_w[frame_word<PACK>(g, lane, h)] ^ (ST_DONE_PSC * 0x01010101u)); any |= m[h]; }
+    if (wave_all_zero(any)) return;
+    const uint32_t x = *reinterpret_cast<const uint32_t *>(msgs + ((size_t)g * E + (size_t)vn_ptr[v]) * kRowBytes + lane * 4);
+    uint32_t r[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), (uint32_t)nz);
+    store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + ((size_t)g * N + (size_t)v) * kRowBytes + lane * 4), pack_halves<PACK>(r), pack_masks<PACK>(m));
+}
+
 // parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome.
 // cn_vnf[k] = variable node of check-edge k, bit 31 set on the last edge of its check; padded with 8
 // zero entries.  A wave walks the run of edges of its checks eight at a time: ONE vector load fetches

@@ -87,7 +87,7 @@ def scenarios(which):
         run("n500_q4_i8", 300, 1.8, {"LUTLDPC_PACK": "1"}, [(True, True), (False, False)])
         run("n500_q4_i8", 1100, 1.8, {}, all3, repeats=3, with_oracle=False)
         run("n500_q4_i8", 1100, 1.8, {"LUTLDPC_VALIDATE": "1"}, all3, with_oracle=False)
-        run("reg36_n1000_mixed", 1025, 2.2, {"LUTLDPC_COMPACT": "1", "LUTLDPC_COMPACT_FIRST": "2", "LUTLDPC_COMPACT_EVERY": "1"}, all3, repeats=3, with_oracle=False)
+        run("reg36_n1000_mixed", 1025, 2.2, {"LUTLDPC_COMPACT": "1", "LUTLDPC_COMPACT_FIRST": "2", "LUTLDPC_COMPACT_EVERY": "1", "LUTLDPC_COMPACT_MARGIN": "0"}, all3, repeats=3, with_oracle=False)
         run("c5_chklut", 20, 4.2, {}, [(True, True)])
         run("dvbs2_q4_i6", 1030, 1.0, {}, [(True, True), (False, False)], repeats=3, with_oracle=False)
         assert fake.fakehip_captures() > 0 and fake.fakehip_graph_launches() > 0 and fake.fakehip_launches_of(b"pass_fused_kernel") > 0
@@ -106,7 +106,7 @@ def scenarios(which):
         done.append("kernel_variants")
     if which in ("all", "skew"):
         # skewed pipeline, graph replay (three calls with one key: plain, capture, replay), compaction, no chain
-        for env in [{}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_COMPACT": "1", "LUTLDPC_COMPACT_FIRST": "2", "LUTLDPC_COMPACT_EVERY": "1"}, {"LUTLDPC_CHAIN": "0"},
+        for env in [{}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_COMPACT": "1", "LUTLDPC_COMPACT_FIRST": "2", "LUTLDPC_COMPACT_EVERY": "1", "LUTLDPC_COMPACT_MARGIN": "0"}, {"LUTLDPC_CHAIN": "0"},
                     {"LUTLDPC_GRAPH": "0"}]:
             for name, B, snr in [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2)]:
                 run(name, B, snr, env, [(True, True), (True, False), (False, False)], repeats=3, with_oracle=False)

@@ -63,10 +63,11 @@ def test_kernel_variants(name, B, snr, env, monkeypatch):
 
 
 @pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2)])
-@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_VALIDATE": "1"}])
+@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_VALIDATE": "1"}, {"LUTLDPC_LATE_HARD": "0"}])
 def test_skewed_pipeline_variants(name, B, snr, env, monkeypatch):
-    """Byte rows, per-class launches instead of the fused pipeline, and the validating debug mode (every role checked
-    against the allocation sizes, one stream synchronisation per fused launch)."""
+    """Byte rows, per-class launches instead of the fused pipeline, the validating debug mode (every role checked against
+    the allocation sizes, one stream synchronisation per fused launch), and decided bits stored by every variable pass
+    instead of recovered at the end (LUTLDPC_LATE_HARD=0)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cd = oracle_codec(name)
@@ -86,6 +87,7 @@ def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
     monkeypatch.setenv("LUTLDPC_COMPACT", "1")
     monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
     monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "2")
+    monkeypatch.setenv("LUTLDPC_COMPACT_MARGIN", "0")          # permute whenever a group falls idle (the default weighs cost against gain)
     cd = oracle_codec(name)
     dec = product_decoder(cd)
     assert dec.describe()["compaction"] == 1
