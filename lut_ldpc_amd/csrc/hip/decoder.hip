@@ -129,8 +129,9 @@ struct lutldpc_decoder {
     // compaction of the surviving frames (kernels_compact.hpp): as-shipped mode, skewed pipeline
     // (off by default: measured on MI355X it does not pay -- DVB-S2 frames finish too late (41.7 of 50 iterations on
     // average), (3,6) frames finish so close together that whole groups fall idle by themselves; LUTLDPC_COMPACT=1)
-    int use_compact = 0, compact_first = 4, compact_every = 0;      // every: 0 = derived from the duration of an iteration
-    float compact_margin = 1.25f;                                   // LUTLDPC_COMPACT_MARGIN (0: permute whenever a group falls idle)
+    int use_compact = -1, compact_first = 8, compact_every = 0;     // use: -1 = automatic (long iterations only), every: 0 = automatic
+    float compact_margin = 1.0f;                                    // LUTLDPC_COMPACT_MARGIN (0: permute whenever a group falls idle)
+    float compact_min_share = 0.35f;                                // ... and at least this share of the live groups falls idle at once
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
@@ -733,13 +734,13 @@ bool skew_eligible(const lutldpc_decoder *d) {
 }
 
 // Are the decided bits of early-terminated frames recovered at the end (hard_from_frozen_kernel) instead of being stored by
-// every variable pass?  Min-sum checks, one message alphabet, no compaction (it drops the messages of finished frames), and
-// -- in the skewed pipeline -- chain fusion on in every iteration or in none (the nodes it updates get their bits from the
-// check pass).  `chain_skip`: those nodes are skipped by the recovery.
+// every variable pass?  Min-sum checks, one message alphabet, and -- in the skewed pipeline -- chain fusion on in every
+// iteration or in none (the nodes it updates get their bits from the check pass).  `chain_skip`: those nodes are skipped by
+// the recovery.  (Compaction drops the messages of finished frames: its check points run the recovery first.)
 bool chain_active(const lutldpc_decoder *d, int set);
 bool late_hard_active(const lutldpc_decoder *d, bool skewed, bool *chain_skip) {
     if (chain_skip) *chain_skip = false;
-    if (!d->late_hard || !d->psc || !d->min_lut || d->use_compact) return false;
+    if (!d->late_hard || !d->psc || !d->min_lut) return false;
     for (int i = 1; i < d->max_iters; i++) if (d->Nq_Msg[(size_t)i] != d->Nq_Msg[0]) return false;
     if (!skewed) return true;
     int on = 0, off = 0;
@@ -910,13 +911,31 @@ constexpr unsigned kPermuteBlocks = 1024;
 // LDS of permute_rows_kernel: the row tiles of four waves + the 16-bit descriptors of every label of the half
 size_t permute_lds_bytes(const lutldpc_decoder *d, int GH) { return (size_t)4 * GH * 64 * sizeof(uint32_t) + (size_t)GH * d->tile() * sizeof(uint16_t); }
 bool compaction_fits(const lutldpc_decoder *d, int GH) { return GH <= kPermuteMaxGroups && permute_lds_bytes(d, GH) <= 64 * 1024; }
+// A check point costs six short launches per half (~30 us) whether it permutes or not: automatic mode switches compaction on
+// only where one iteration of the batch lasts long enough to make that noise (estimated from its row traffic at 5.5 TB/s);
+// LUTLDPC_COMPACT=1 / 0 forces it on / off.
+bool compaction_on(const lutldpc_decoder *d, int G) {
+    if (!compaction_fits(d, (G + 1) / 2) || G < 4) return false;
+    if (d->use_compact >= 0) return d->use_compact != 0;
+    const double est_iter_us = (4.0 * d->E + 3.0 * d->nvar) * kRowBytes * G / 5.5e6;
+    return est_iter_us >= 400.0;
+}
 int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     Timed t(d, LUTLDPC_K_LAYOUT);
     const int T = d->tile(), s0 = h.g0 * T, n = h.G * T;
     if (n <= 0) return LUTLDPC_OK;
     uint8_t *pending = d->d_vfail.p + (size_t)((ii + 1) & 1) * kVfailSlots * d->Bcap;      // flags already raised for the next test
-    hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n, T,
-                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, d->d_ctl.p + 4 * hf, d->max_iters - 1 - ii, d->compact_margin);
+    int32_t *ctl = d->d_ctl.p + 4 * hf;
+    hipLaunchKernelGGL(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
+                       d->compact_margin > 0 ? d->compact_min_share : 0.0f);
+    bool chain_skip = false;
+    const bool late = late_hard_active(d, true, &chain_skip);
+    if (late)      // the decided bits of the frames that left since the last permutation, before their messages are dropped
+        PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((d->nvar + 3) / 4)), (unsigned)h.G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
+                                            reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, d->nvar, d->E,
+                                            d->Nq_Msg[0] / 2, h.g0, ctl));
+    hipLaunchKernelGGL(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
+                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, late ? 1 : 0);
     const size_t lds = permute_lds_bytes(d, h.G);
     auto rows = [&](uint8_t *buf, int n_rows, int gather) {
         const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((n_rows + 3) / 4));
@@ -1000,9 +1019,8 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
     const lutldpc_decoder::SkewPlan &plan = *pp;
     // compaction of the surviving frames: check points every `every` iterations (a check point costs four short launches
     // per half: keep that below a few per cent of an iteration, whose duration is estimated from its row traffic)
-    const bool compact = psc && d->use_compact && compaction_fits(d, half[0].G);
-    const double est_iter_us = (4.0 * d->E + 3.0 * d->nvar) * kRowBytes * G / 5.5e6;
-    const int every = d->compact_every > 0 ? d->compact_every : std::max(2, std::min(16, (int)std::ceil(60.0 / std::max(est_iter_us, 1.0))));
+    const bool compact = psc && compaction_on(d, G);
+    const int every = d->compact_every > 0 ? d->compact_every : 2;
     if (compact) {
         Timed t(d, LUTLDPC_K_LAYOUT);
         hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
@@ -1066,8 +1084,9 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         bool chain_skip = false;
         if (late_hard_active(d, skewed, &chain_skip)) {
             Timed t(d, LUTLDPC_K_LAYOUT);
-            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
-                                                reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, N, E, d->Nq_Msg[0] / 2));
+            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(2048u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
+                                                reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, N, E, d->Nq_Msg[0] / 2,
+                                                0, (const int32_t *)nullptr));
             LAUNCH_CHECK();
         }
     }
@@ -1076,7 +1095,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     const int fsel = skewed ? (I & 1) : 0;            // the flag buffer no pass of the skewed pipeline has written since its last test
     if ((rc = launch_syndrome(d, G, fsel))) return rc;
     if ((rc = launch_state(d, B, Bpad, 3, I, 0, -1, fsel))) return rc;
-    if (skewed && d->psc && d->use_compact && compaction_fits(d, (G + 1) / 2)) {
+    if (skewed && d->psc && compaction_on(d, G)) {
         const HalfRange half[2] = {{0, (G + 1) / 2}, {(G + 1) / 2, G - (G + 1) / 2}};
         if ((rc = launch_uncompaction(d, half, Bpad))) return rc;
     }
@@ -1193,7 +1212,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << d->use_compact << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 
@@ -1279,6 +1298,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT_EVERY")) { int v = atoi(e); if (v >= 1) d->compact_every = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT_MARGIN")) { double v = atof(e); if (v >= 0 && v < 100) d->compact_margin = (float)v; }
+    if (const char *e = getenv("LUTLDPC_COMPACT_MIN_SHARE")) { double v = atof(e); if (v >= 0 && v <= 1) d->compact_min_share = (float)v; }
     if (const char *e = getenv("LUTLDPC_GRAPH")) d->use_graph = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_PRIO")) d->fused_prio = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_TAIL_FRONT")) { double v = atof(e); if (v >= 0 && v < 0.9) d->tail_front = v; }

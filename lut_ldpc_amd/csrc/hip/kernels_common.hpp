@@ -39,6 +39,7 @@ constexpr int kMaxSeg = 32;          // degree classes handled by one pass launc
 
 // frame states
 constexpr uint32_t ST_ACTIVE = 0, ST_DONE_PSC = 1, ST_DONE_PISC = 2, ST_PAD = 3;
+constexpr uint32_t ST_DONE_SAVED = 4;   // left through the exit test, decided bits already recovered into the hard rows (compaction)
 
 struct PassSeg {
     int32_t block_begin;   // first block (within one frame group) of this degree class

@@ -9,14 +9,18 @@
 // decided bits and iteration codes are put back into the original order.  Only the message and channel rows
 // of the ACTIVE frames are moved (finished frames never read theirs again).
 //
-// One permutation = compact_plan_kernel (one block per half: prefix sum, small per-slot arrays) +
+// One permutation = compact_apply_kernel (one block per half: prefix sum, small per-slot arrays) +
 // permute_rows_kernel over the E message rows, the N channel rows and the N decided-bit rows.
 //
 // Whether a permutation pays is decided ON THE DEVICE at every check point (the launch sequence is a fixed hipGraph): it
-// moves  (live + new) groups of message / channel rows  and all decided-bit rows, about  0.35 (live + new) + 0.15 GH
-// iteration-equivalents of row traffic, and saves  (live - new) groups x remaining iterations.  compact_plan_kernel
-// permutes only when the saving exceeds 1.25 x that cost; otherwise the row kernels of the check point return at once
-// (a few microseconds per check point).
+// moves  (live + new) groups of message / channel rows  and all decided-bit rows -- measured 1.4 ms for half a 16384-frame
+// DVB-S2 batch, about  0.7 (live + new) + 0.3 GH  group-iterations -- and saves  (live - new) groups x remaining
+// iterations.  compact_decide_kernel permutes only when a sizeable share of the live groups falls idle at once and the
+// saving exceeds the cost; otherwise the other kernels of the check point return at once (5 us each).
+//
+// A check point = compact_decide_kernel -> hard_from_frozen_kernel (the decided bits of the frames that left since the
+// last permutation are read off their frozen messages BEFORE those are dropped, kernels_generic.hpp) ->
+// compact_apply_kernel -> permute_rows_kernel x 3.
 #pragma once
 #include "kernels_common.hpp"
 
@@ -29,19 +33,15 @@ __global__ __launch_bounds__(256) void compact_init_kernel(int32_t *__restrict__
     if (i == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = gh0; ctl[3] = gh0; ctl[4] = 0; ctl[5] = 1; ctl[6] = gh1; ctl[7] = gh1; }
 }
 
-// Slots [s0, s0 + n): perm[new] = old (absolute slot numbers), active frames first.  Applies the permutation to
-// state / iters / frame_of and to the pending flag buffer (its kVfailSlots copies are ORed into copy 0).
-// tmp: 3 * n int32 of scratch.  ctl = {n_active, skip, live groups, live groups before this permutation} of this half.
-// iters_left: message-passing iterations still to run after this check point; margin: permute when saving >= margin x cost
-// (1.25; 0 = whenever a group falls idle, for the tests).
-__global__ __launch_bounds__(1024) void compact_plan_kernel(uint8_t *__restrict__ state, int32_t *__restrict__ iters, int32_t *__restrict__ frame_of,
-                                                             uint8_t *__restrict__ vfail_pending, int vfail_stride, int s0, int n, int tile_frames,
-                                                             int32_t *__restrict__ perm, int32_t *__restrict__ tmp, int32_t *__restrict__ ctl, int iters_left, float margin)
+// Check point, step 1 (one block): count the active frames of the half and decide.  ctl = {n_active, skip, live groups, live
+// groups before this permutation}.  iters_left: message-passing iterations still to run; a permutation happens when at least
+// `min_share` of the live groups fall idle AND the group-iterations saved reach `margin` x the rows moved (header of this
+// file; margin 0 = whenever a group falls idle, for the tests).
+__global__ __launch_bounds__(1024) void compact_decide_kernel(const uint8_t *__restrict__ state, int s0, int n, int tile_frames, int32_t *__restrict__ ctl,
+                                                               int iters_left, float margin, float min_share)
 {
     __shared__ int wsum[16];
-    __shared__ int base_act, base_rest, total_act;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // pass 1: count the active frames
     int cnt = 0;
     for (int i = t; i < n; i += 1024) cnt += state[s0 + i] == ST_ACTIVE ? 1 : 0;
     for (int o = 32; o; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -50,19 +50,33 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(uint8_t *__restrict_
     if (t == 0) {
         int s = 0;
         for (int k = 0; k < 16; k++) s += wsum[k];
-        total_act = s; base_act = 0; base_rest = s;
-        // permute only when the groups that fall idle save more row traffic over the remaining iterations than moving
-        // the survivors costs (see the header of this file)
         const int gnew = (s + tile_frames - 1) / tile_frames, live = ctl[2], gh = n / tile_frames;
         const float gain = (float)(live - gnew) * (float)iters_left;
-        const float cost = 0.35f * (float)(live + gnew) + 0.15f * (float)gh;
+        const float cost = 0.7f * (float)(live + gnew) + 0.3f * (float)gh;
         ctl[0] = s;
-        if (gnew < live && gain >= margin * cost) { ctl[1] = 0; ctl[3] = live; ctl[2] = gnew; } else ctl[1] = 1;
-        total_act = ctl[1];                     // (re-used as the block-wide skip flag)
+        if (gnew < live && (float)(live - gnew) >= min_share * (float)live && gain >= margin * cost) { ctl[1] = 0; ctl[3] = live; ctl[2] = gnew; }
+        else ctl[1] = 1;
     }
+}
+
+// Check point, step 3 (one block; step 2 is hard_from_frozen_kernel on the frames that left since the last permutation):
+// slots [s0, s0 + n): perm[new] = old (absolute slot numbers), active frames first (stable).  Applies the permutation to
+// state / iters / frame_of and to the pending flag buffer (its kVfailSlots copies are ORed into copy 0).  Frames that left
+// through the exit test are marked ST_DONE_SAVED first: their decided bits are in the hard rows now, their messages may go.
+// tmp: 3 * n int32 of scratch.
+__global__ __launch_bounds__(1024) void compact_apply_kernel(uint8_t *__restrict__ state, int32_t *__restrict__ iters, int32_t *__restrict__ frame_of,
+                                                              uint8_t *__restrict__ vfail_pending, int vfail_stride, int s0, int n,
+                                                              int32_t *__restrict__ perm, int32_t *__restrict__ tmp, const int32_t *__restrict__ ctl, int mark_saved)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_act, base_rest;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (ctl[1]) return;                                       // nothing to gain at this check point
+    if (t == 0) { base_act = 0; base_rest = ctl[0]; }
+    if (mark_saved)
+        for (int i = t; i < n; i += 1024) if (state[s0 + i] == ST_DONE_PSC) state[s0 + i] = ST_DONE_SAVED;
     __syncthreads();
-    if (total_act) return;
-    // pass 2: stable partition, 1024 slots at a time
+    // stable partition, 1024 slots at a time
     for (int c0 = 0; c0 < n; c0 += 1024) {
         const int i = c0 + t;
         const int act = (i < n && state[s0 + i] == ST_ACTIVE) ? 1 : 0, val = i < n ? 1 : 0;
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(uint8_t *__restrict_
     }
     __threadfence_block();
     __syncthreads();
-    // pass 3: move the per-slot data (through tmp: the permutation is not in place)
+    // move the per-slot data (through tmp: the permutation is not in place)
     for (int i = t; i < n; i += 1024) {
         const int o = perm[s0 + i];
         uint8_t vf = 0;

@@ -409,23 +409,32 @@ __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__
 // (chk_update_minsum, :355-402: sign_msg = sign_prod ^ own sign, sign_prod = 0), i.e. the unanimous sign of the variable
 // node: bit v = (label on the node's first edge < nz).  Exact for min-sum check updates with one message alphabet; the
 // nodes updated inside the check pass (chain fusion, `skip`) keep the bits that pass stored for them.
+// g0: first frame group of the launch (grid.y groups from there); ctl: when given (a compaction check point), ctl[1] != 0
+// means "no permutation at this check point": nothing to save yet.
 template <int PACK>
 __global__ __launch_bounds__(256) void hard_from_frozen_kernel(const uint8_t *__restrict__ msgs, uint8_t *__restrict__ hard,
                                                                const uint32_t *__restrict__ state_w, const int32_t *__restrict__ vn_ptr,
-                                                               const uint8_t *__restrict__ skip, int N, int E, int nz)
+                                                               const uint8_t *__restrict__ skip, int N, int E, int nz, int g0, const int32_t *__restrict__ ctl)
 {
-    const int lane = threadIdx.x & 63, g = blockIdx.y;
-    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (v >= N || (skip && skip[v])) return;
+    if (ctl && ctl[1]) return;
+    const int lane = threadIdx.x & 63, g = g0 + blockIdx.y;
+    // which frames of this lane left through the exit test: the same for every node of the group
     uint32_t m[PACK], any = 0;
 #pragma unroll
     for (int h = 0; h < PACK; h++) { m[h] = swar_zero_mask(state_w[frame_word<PACK>(g, lane, h)] ^ (ST_DONE_PSC * 0x01010101u)); any |= m[h]; }
     if (wave_all_zero(any)) return;
-    const uint32_t x = *reinterpret_cast<const uint32_t *>(msgs + ((size_t)g * E + (size_t)vn_ptr[v]) * kRowBytes + lane * 4);
-    uint32_t r[PACK];
+    const uint32_t smask = pack_masks<PACK>(m);
+    // a small fixed grid walks the nodes (a check point that does not permute must cost microseconds)
+    const int w0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), step = (int)gridDim.x * 4;
+#pragma unroll 4
+    for (int v = w0; v < N; v += step) {
+        if (skip && skip[v]) continue;
+        const uint32_t x = *reinterpret_cast<const uint32_t *>(msgs + ((size_t)g * E + (size_t)vn_ptr[v]) * kRowBytes + lane * 4);
+        uint32_t r[PACK];
 #pragma unroll
-    for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), (uint32_t)nz);
-    store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + ((size_t)g * N + (size_t)v) * kRowBytes + lane * 4), pack_halves<PACK>(r), pack_masks<PACK>(m));
+        for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), (uint32_t)nz);
+        store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + ((size_t)g * N + (size_t)v) * kRowBytes + lane * 4), pack_halves<PACK>(r), smask);
+    }
 }
 
 // parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome.

@@ -1,6 +1,6 @@
 #!/bin/bash
-# As-shipped mode (parity_check_iter = true) with and without compaction of the surviving frames, per workload, beside the
-# fixed-work number of the same box.  Usage: tools/shipped_ab.sh [workload...]   -> gpurun_out/shipped_ab.txt
+# As-shipped mode (parity_check_iter = true) with compaction of the surviving frames forced off / automatic / forced on, per
+# workload, beside the fixed-work number of the same box.  Usage: tools/shipped_ab.sh [workload...]   -> gpurun_out/shipped_ab.txt
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/shipped_ab.txt; : > "$out"
 run() {   # label, env..., -- bench args
@@ -15,7 +15,8 @@ print('$label', '%.1f k cw/s' % (d['value']/1e3), 'iters %.1f' % d['config']['me
 for wl in ${@:-dvbs2 twin c2 c1}; do
     for rep in 1 2; do
         run "$wl fixed" X=1 -- --workload $wl --mode fixed
-        run "$wl shipped" X=1 -- --workload $wl --mode shipped
-        run "$wl shipped+compact" LUTLDPC_COMPACT=1 -- --workload $wl --mode shipped
+        run "$wl shipped,compaction-off" LUTLDPC_COMPACT=0 -- --workload $wl --mode shipped
+        run "$wl shipped,default" X=1 -- --workload $wl --mode shipped
+        run "$wl shipped,compaction-on" LUTLDPC_COMPACT=1 -- --workload $wl --mode shipped
     done
 done
