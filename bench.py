@@ -107,11 +107,20 @@ class PowerSampler:
     sample, no GPU access).  Identical runs land on discrete throughput levels per process; the
     samples say whether a level comes with a different clock or power.  Silent when the files are not there."""
 
-    def __init__(self, period_s=0.01):
+    def __init__(self, period_s=0.01, pci=None):
         import glob
         self.period = period_s
-        self.power = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))[:1]
-        self.sclk = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))[:1]
+        # the hwmon directory of THIS GPU (a box shows the cards of the whole host): by PCI address when known
+        roots = []
+        if pci:
+            roots = sorted(glob.glob(f"/sys/bus/pci/devices/{pci}/hwmon/hwmon*"))
+        if not roots:
+            roots = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.card = roots[0] if roots else None
+        self.matched_by_pci = bool(pci and roots and pci in roots[0]) or bool(pci and roots and "/sys/bus/pci/devices/" in roots[0])
+        pick = lambda names: [f"{self.card}/{n}" for n in names if self.card and os.path.exists(f"{self.card}/{n}")][:1]
+        self.power = pick(["power1_average", "power1_input"])
+        self.sclk = pick(["freq1_input"])
         self.samples = []
         self._stop = False
         self._thr = None
@@ -145,7 +154,7 @@ class PowerSampler:
         if not pw and not ck:
             return None
         q = lambda v, f: float(np.percentile(v, f)) if v else None
-        return {"samples": len(self.samples), "socket_power_W": {"median": q(pw, 50), "p10": q(pw, 10), "p90": q(pw, 90)},
+        return {"samples": len(self.samples), "hwmon": self.card, "matched_by_pci_address": self.matched_by_pci, "socket_power_W": {"median": q(pw, 50), "p10": q(pw, 10), "p90": q(pw, 90)},
                 "sclk_MHz": {"median": q(ck, 50), "p10": q(ck, 10), "p90": q(ck, 90)}}
 
 
@@ -313,7 +322,12 @@ def main():
     step_stats = None
     if args.reps > 0:
         ts = []
-        with PowerSampler() as ps:
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pci = None
+        with PowerSampler(pci=pci) as ps:
             for _ in range(args.reps):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()

@@ -104,6 +104,11 @@ int lutldpc_de_threshold(const int32_t *dl, const double *lam, int nl, const int
                          double thr_min, double thr_prec, double Pe_max, int maxiter_bisec, int max_ni_de_iters,
                          double LLR_max, int Nq_fine, double *thr_out);
 
+/* The [BP] path's front end (LDPC_BER_Sim_BP::sim_batch): BPSK over AWGN in double precision on the host, Philox-addressed per
+ * (seed, stream = SNR index, frame, bit pair), Box-Muller; llr[B*N] = 4 x / N0 (src/LDPC_BER_Sim.cpp:270-279), uncoded[B] =
+ * slicer errors (:283).  codewords: B*N sent bits or NULL (all-zero codeword). */
+int lutldpc_awgn_llr(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const uint8_t *codewords, double *llr, int32_t *uncoded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,5 +7,6 @@ LDPC_Code_LUT / LDPC_BER_Sim_LUT) and the `ber_sim` CLI next to it.  This packag
 from ._capi import LutLdpcError, device_count, last_error, LIB_PATH  # noqa: F401
 from .decoder import Decoder  # noqa: F401
 from .codec import Codec, de_threshold  # noqa: F401
+from .bp import BPDecoder  # noqa: F401
 
-__all__ = ["Decoder", "Codec", "de_threshold", "LutLdpcError", "device_count", "last_error", "LIB_PATH"]
+__all__ = ["Decoder", "Codec", "BPDecoder", "de_threshold", "LutLdpcError", "device_count", "last_error", "LIB_PATH"]

@@ -12,6 +12,7 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 namespace fs = std::filesystem;
 
@@ -321,7 +322,7 @@ void LDPC_BER_Sim_LUT::sim_batch(double snr, int snr_index, int64_t frame0, int 
     for (int i = 0; i < B && !cha_dump.empty(); i++) C->print_stimuli(&cha_dump[(size_t)i * N], &bits_dump[(size_t)i * N]);
 }
 
-bool LDPC_BER_Sim_LUT::sim_snr_point(double snr, int snr_index) {
+bool LDPC_BER_Sim::sim_snr_point(double snr, int snr_index) {
     const int N = codeword_length, K = dataword_length;
     SnrPointCounters c;
     const int64_t total = (int64_t)Nframes;
@@ -345,6 +346,118 @@ bool LDPC_BER_Sim_LUT::sim_snr_point(double snr, int snr_index) {
                   << " FER: " << fer << std::endl << std::flush;
     results.add_snr_point(snr, c.frames, c.databits, c.frame_errors, c.data_bit_errors, c.uncoded_bit_errors);
     return ber < ber_min || fer < fer_min;       // :307
+}
+
+// ------------------------------------------------------------------ LDPC_BER_Sim_BP
+void awgn_llr_frames(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const unsigned char *codewords, double *llr, int32_t *uncoded) {
+    const double sigma = std::sqrt(N0 / 2), two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < B; i++) {
+        const uint64_t frame = frame0 + (uint64_t)i;
+        int32_t unc = 0;
+        for (int p = 0; p < (N + 1) / 2; p++) {
+            // one Philox block per bit pair: two 53-bit uniforms -> one Box-Muller pair
+            uint32_t c[4] = {(uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)p, stream | 0x40000000u};
+            uint32_t ka = (uint32_t)seed, kb = (uint32_t)(seed >> 32);
+            for (int r = 0; r < 10; r++) { philox_round(c, ka, kb); ka += 0x9E3779B9u; kb += 0xBB67AE85u; }
+            const double u1 = ((double)((((uint64_t)c[0] << 32) | c[1]) >> 11) + 1.0) * (1.0 / 9007199254740992.0);    // (0, 1]
+            const double u2 = (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);            // [0, 1)
+            const double rad = std::sqrt(-2.0 * std::log(u1));
+            double sn, cs;
+            ::sincos(two_pi * u2, &sn, &cs);       // ONE libm entry point for both (a compiler may or may not merge sin + cos itself)
+            const double z[2] = {rad * cs, rad * sn};
+            for (int k = 0; k < 2 && 2 * p + k < N; k++) {
+                const int v = 2 * p + k;
+                const int bit = codewords ? codewords[(size_t)i * N + v] : 0;
+                const double x = (bit ? -1.0 : 1.0) + sigma * z[k];
+                llr[(size_t)i * N + v] = 4.0 * x / N0;
+                unc += ((x < 0) ? 1 : 0) != bit;
+            }
+        }
+        uncoded[i] = unc;
+    }
+}
+
+LDPC_BER_Sim_BP::LDPC_BER_Sim_BP(const std::string &params, const std::string &base) : LDPC_BER_Sim(params, base) {
+    Ini ini(params);
+    max_iter = ini.get("BP.max_iter", 30);
+    llr_calc_d1 = ini.get("BP.qllr_scale_res", 12);
+    llr_calc_d2 = ini.get("BP.qllr_table_size", 300);
+    llr_calc_d3 = ini.get("BP.qllr_spacing_res", 7);
+    llr_calc_d4 = ini.get("BP.qllr_total_res", 28);           // 8 * sizeof(QLLR) - 4
+}
+
+LDPC_BER_Sim_BP::~LDPC_BER_Sim_BP() { if (dec) lutldpc_bp_destroy(dec); }
+
+void LDPC_BER_Sim_BP::load() {
+    if (!codec_filename.empty())
+        throw std::runtime_error("LDPC_BER_Sim::load(): loading an IT++ bp_codec.it file is not supported (the IT++ fork's file layout is absent); give LDPC.parity_filename");
+    const fs::path parity_path = fs::path(codes_path) / (parity_filename + ".alist");
+    if (!fs::exists(parity_path)) throw std::runtime_error("Parity file" + parity_path.string() + " does not exist!");
+    H.reset(new LDPC_Parity(parity_path.string()));
+    if (!zero_codeword) {
+        const fs::path gen_path = fs::path(codes_path) / (parity_filename + ".gen.it");
+        G.reset(new LDPC_Generator_Systematic());
+        if (fs::exists(gen_path)) G->load(gen_path.string());
+        if (!G->is_initialized()) {
+            G->construct(H.get());
+            if (save_permuted) {
+                H->save_alist(parity_path.string());
+                { it_file_writer f(gen_path.string()); f.write("Fileversion", 2); f.close(); }
+                G->save(gen_path.string());
+            }
+        }
+        encoder_set = true;
+    }
+    // the decoder sees the (possibly column-permuted) matrix through the same index arrays as the LUT decoder
+    LDPC_Code_LUT graph;
+    graph.set_device(-1);
+    graph.set_code_with_rank(H.get(), nullptr, H->get_ncheck());
+    if (lutldpc_bp_create(graph.get_nvar(), graph.get_nchk(), graph.get_dv_vec().data(), graph.get_dc_vec().data(), graph.get_cn_msg_idx().data(),
+                          llr_calc_d1, llr_calc_d2, llr_calc_d3, llr_calc_d4, device, &dec) != LUTLDPC_OK)
+        throw std::runtime_error(std::string("LDPC_BER_Sim::load(): ") + lutldpc_last_error());
+    lutldpc_bp_set_exit_conditions(dec, max_iter, parity_check_iter, parity_check_iter);     // :199
+    codeword_length = H->get_nvar();
+    dataword_length = H->get_nvar() - H->get_ncheck();         // itpp::LDPC_Code::get_ninfo()
+    code_rate = 1.0 - (double)H->get_ncheck() / H->get_nvar(); // itpp::LDPC_Code::get_rate()
+    decoder_set = true;
+    results = LDPC_BER_Sim_Results(codeword_length, codeword_length - dataword_length);
+}
+
+void LDPC_BER_Sim_BP::sim_batch(double snr, int snr_index, int64_t frame0, int B, FrameStats *stats) {
+    const int N = codeword_length, K = dataword_length;
+    const double N0 = std::pow(10.0, -snr / 10.0) / code_rate;      // :248
+    const uint64_t seed = (uint64_t)(int64_t)(rand_seed + rand_seed_offset);
+    if (!zero_codeword && !encoder_set) throw std::runtime_error("Non zero codewords require the encoder to be set!");
+    std::vector<unsigned char> codewords;
+    if (!zero_codeword) {
+        bvec info((size_t)K), cw;
+        codewords.resize((size_t)B * N);
+        for (int i = 0; i < B; i++) {
+            random_info_bits(seed, (uint32_t)snr_index, (uint64_t)(frame0 + i), K, info.data());
+            G->encode(info, cw);
+            std::memcpy(&codewords[(size_t)i * N], cw.data(), (size_t)N);
+        }
+    }
+    std::vector<double> llr((size_t)B * N);
+    std::vector<int32_t> unc((size_t)B), iters((size_t)B);
+    std::vector<uint8_t> bits((size_t)B * N);
+    // the noise of a batch is generated on all host cores (frames are Philox-addressed: any split gives the same samples)
+    const unsigned nthr = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; t++)
+        pool.emplace_back([&, t] {
+            const int b0 = (int)((int64_t)B * t / nthr), b1 = (int)((int64_t)B * (t + 1) / nthr);
+            if (b1 > b0) awgn_llr_frames(seed, (uint32_t)snr_index, (uint64_t)(frame0 + b0), b1 - b0, N, N0, codewords.empty() ? nullptr : &codewords[(size_t)b0 * N],
+                                         &llr[(size_t)b0 * N], &unc[(size_t)b0]);
+        });
+    for (auto &th : pool) th.join();
+    if (lutldpc_bp_decode_llr_batch(dec, llr.data(), B, bits.data(), iters.data(), nullptr) != LUTLDPC_OK)
+        throw std::runtime_error(std::string("LDPC_BER_Sim::sim_snr_point(): ") + lutldpc_last_error());
+    for (int i = 0; i < B; i++) {
+        int be = 0;
+        for (int v = 0; v < K; v++) be += bits[(size_t)i * N + v] != (codewords.empty() ? 0 : codewords[(size_t)i * N + v]);
+        stats[i] = FrameStats{iters[(size_t)i], be ? 1 : 0, be, unc[(size_t)i]};
+    }
 }
 
 // ------------------------------------------------------------------ ber_sim main
@@ -392,8 +505,7 @@ int ber_sim_main(int argc, char **argv) {
         const std::string codec_type = ini.get("Sim.codec_type", "none");
         std::unique_ptr<LDPC_BER_Sim> sim;
         if (ini.has_section("LUT") || codec_type == "LUT") sim.reset(new LDPC_BER_Sim_LUT(params_path, base_dir));
-        else if (ini.has_section("BP") || codec_type == "BP")
-            throw std::runtime_error("the [BP] comparison decoder (IT++ LDPC_Code) is outside this build's scope; use a [LUT] section");
+        else if (ini.has_section("BP") || codec_type == "BP") sim.reset(new LDPC_BER_Sim_BP(params_path, base_dir));
         else throw std::runtime_error("You must specify the type of decoder in the params file ([LUT] section or Sim.codec_type)");
         sim->rand_seed = seed;
         sim->device = device;

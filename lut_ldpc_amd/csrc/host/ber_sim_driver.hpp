@@ -8,10 +8,12 @@
 //     MORE than Nfers frame errors were seen) is applied to the per-frame results in frame order,
 //     so the counters are exactly what a frame-by-frame loop over the same frames would give;
 //   * random numbers are Philox-addressed per (seed, SNR index, frame), see kernels_frontend.hpp;
-//   * the [BP] branch (IT++'s own BP decoder, src/LDPC_BER_Sim.cpp:157-244) is out of scope.
+//   * the [BP] branch (IT++'s own BP decoder, src/LDPC_BER_Sim.cpp:157-244) is LDPC_BER_Sim_BP: the comparison decoder of
+//     include/lut_ldpc_bp.h on the device behind a host AWGN front end (PARITY UNPINNED: the IT++ fork is absent).
 #pragma once
 #include "ldpc_code_lut.hpp"
 #include "lut_ldpc_hip.h"
+#include "lut_ldpc_bp.h"
 
 #include <cstdint>
 #include <functional>
@@ -65,7 +67,12 @@ public:
     virtual void run();                                          // :121-155
     virtual void save();                                         // :317-340
     std::string results_file_path() const;                       // <results_dir>/<gen_filename>/<gen_filename>_rseedNNNN.it
-    virtual bool sim_snr_point(double snr, int snr_index) = 0;   // :246-311
+    virtual bool sim_snr_point(double snr, int snr_index);       // :246-311 (batched through sim_batch)
+    // frames frame0 .. frame0+B-1 of SNR point `snr_index` (any order, any sharding): the body of the
+    // frame loop, :262-286.  The stop rule is applied by the caller (accumulate_in_order).
+    virtual void sim_batch(double snr, int snr_index, int64_t frame0, int B, FrameStats *stats) = 0;
+    int get_codeword_length() const { return codeword_length; }
+    int get_dataword_length() const { return dataword_length; }
     virtual std::string gen_filename() const;                    // :104-115
     void append_custom_name(const std::string &ext) { custom_name += ext; }
 
@@ -96,13 +103,8 @@ class LDPC_BER_Sim_LUT : public LDPC_BER_Sim {
 public:
     LDPC_BER_Sim_LUT(const std::string &params_file_path, const std::string &base_dir_path);   // src/LDPC_BER_Sim.cpp:376-430
     void load() override;                                        // :434-550
-    bool sim_snr_point(double snr, int snr_index) override;
-    // frames frame0 .. frame0+B-1 of SNR point `snr_index` (any order, any sharding): the body of the
-    // frame loop, :262-286.  The stop rule is applied by the caller (accumulate_in_order).
-    void sim_batch(double snr, int snr_index, int64_t frame0, int B, FrameStats *stats);
+    void sim_batch(double snr, int snr_index, int64_t frame0, int B, FrameStats *stats) override;
     std::string gen_filename() const override;                   // :553-568
-    int get_codeword_length() const { return codeword_length; }
-    int get_dataword_length() const { return dataword_length; }
     LDPC_Code_LUT *codec() { return C.get(); }
 
     std::optional<double> design_thr, design_SNRdB;
@@ -120,6 +122,29 @@ private:
     std::unique_ptr<LDPC_Parity> H;
     std::unique_ptr<LDPC_Generator_Systematic> G;
     std::unique_ptr<LDPC_Code_LUT> C;
+};
+
+// BPSK over AWGN in double precision on the host, Philox-addressed per (seed, stream = SNR index, frame, bit pair), Box-Muller:
+// llr[i*N + v] = 4 x / N0 with x = (1 - 2 bit) + sqrt(N0/2) z  (src/LDPC_BER_Sim.cpp:270-279, BPSK::demodulate_soft_bits);
+// codewords: B*N sent bits or NULL for the all-zero codeword; uncoded[i] = slicer errors of frame i (:283).
+void awgn_llr_frames(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const unsigned char *codewords,
+                     double *llr, int32_t *uncoded);
+
+// The reference's base class as it is used for the [BP] section (src/LDPC_BER_Sim.cpp:157-244): itpp::LDPC_Code with
+// LLR_calc_unit(qllr_scale_res, qllr_table_size, qllr_spacing_res, qllr_total_res) -> lutldpc_bp_decoder.
+class LDPC_BER_Sim_BP : public LDPC_BER_Sim {
+public:
+    LDPC_BER_Sim_BP(const std::string &params_file_path, const std::string &base_dir_path);   // :42-102
+    ~LDPC_BER_Sim_BP() override;
+    void load() override;                                        // :157-244
+    void sim_batch(double snr, int snr_index, int64_t frame0, int B, FrameStats *stats) override;
+    int llr_calc_d1 = 12, llr_calc_d2 = 300, llr_calc_d3 = 7, llr_calc_d4 = 28;                // :75-78
+    lutldpc_bp_decoder *decoder() { return dec; }
+
+private:
+    std::unique_ptr<LDPC_Parity> H;
+    std::unique_ptr<LDPC_Generator_Systematic> G;
+    lutldpc_bp_decoder *dec = nullptr;
 };
 
 // ber_sim's main (prog/ber_sim.cpp:46-160): returns the process exit code

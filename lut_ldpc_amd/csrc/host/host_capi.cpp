@@ -2,6 +2,7 @@
 #include "lut_ldpc_host.h"
 #include "ldpc_code_lut.hpp"
 #include "ber_sim_driver.hpp"
+#include "ini.hpp"
 
 #include <cmath>
 #include <vector>
@@ -219,12 +220,22 @@ int lutldpc_codec_channel_cells(lutldpc_codec *c, double snr_db, uint64_t *thr, 
     return rc == LUTLDPC_OK ? n : rc;
 }
 
+// prog/ber_sim.cpp:128-142: the section present in the parameter file (or Sim.codec_type) picks the simulation class
+static std::unique_ptr<LDPC_BER_Sim> make_sim(const char *params_path, const char *base_dir) {
+    Ini ini(params_path);
+    const std::string codec_type = ini.get("Sim.codec_type", "none");
+    if (ini.has_section("LUT") || codec_type == "LUT") return std::unique_ptr<LDPC_BER_Sim>(new LDPC_BER_Sim_LUT(params_path, base_dir));
+    if (ini.has_section("BP") || codec_type == "BP") return std::unique_ptr<LDPC_BER_Sim>(new LDPC_BER_Sim_BP(params_path, base_dir));
+    throw std::runtime_error("You must specify the type of decoder in the params file ([LUT] or [BP] section, or Sim.codec_type)");
+}
+
 int lutldpc_ber_sim_run(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device, int save_results, int quiet,
                         double *snr, int64_t *counters, int cap) {
     int n = 0;
     int rc = guarded([&] {
         if (!params_path || !base_dir) throw std::invalid_argument("NULL argument");
-        LDPC_BER_Sim_LUT sim(params_path, base_dir);
+        std::unique_ptr<LDPC_BER_Sim> simp = make_sim(params_path, base_dir);
+        LDPC_BER_Sim &sim = *simp;
         sim.rand_seed = seed; sim.device = device; sim.quiet = quiet != 0;
         if (custom_name) sim.append_custom_name(custom_name);
         sim.load();
@@ -247,13 +258,21 @@ int lutldpc_ber_sim_run(const char *params_path, const char *base_dir, int seed,
 
 int lutldpc_ber_sim_main(int argc, char **argv) { return ber_sim_main(argc, argv); }
 
-struct lutldpc_bersim { std::unique_ptr<LDPC_BER_Sim_LUT> sim; };
+int lutldpc_awgn_llr(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const uint8_t *codewords, double *llr, int32_t *uncoded) {
+    return guarded([&] {
+        if (!llr || !uncoded || B <= 0 || N <= 0 || !(N0 > 0)) throw std::invalid_argument("NULL / bad argument");
+        awgn_llr_frames(seed, stream, frame0, B, N, N0, codewords, llr, uncoded);
+        return LUTLDPC_OK;
+    });
+}
+
+struct lutldpc_bersim { std::unique_ptr<LDPC_BER_Sim> sim; };
 
 int lutldpc_bersim_create(const char *params_path, const char *base_dir, int seed, const char *custom_name, int device, lutldpc_bersim **out) {
     return guarded([&] {
         if (!params_path || !base_dir || !out) throw std::invalid_argument("NULL argument");
         std::unique_ptr<lutldpc_bersim> s(new lutldpc_bersim);
-        s->sim.reset(new LDPC_BER_Sim_LUT(params_path, base_dir));
+        s->sim = make_sim(params_path, base_dir);
         s->sim->rand_seed = seed; s->sim->device = device; s->sim->quiet = true;
         if (custom_name) s->sim->append_custom_name(custom_name);
         s->sim->load();
@@ -265,7 +284,7 @@ int lutldpc_bersim_destroy(lutldpc_bersim *s) { delete s; return LUTLDPC_OK; }
 int lutldpc_bersim_info(lutldpc_bersim *s, int64_t *info, double *limits, double *snr, int snr_cap) {
     return guarded([&] {
         if (!s || !info || !limits) throw std::invalid_argument("NULL argument");
-        LDPC_BER_Sim_LUT &m = *s->sim;
+        LDPC_BER_Sim &m = *s->sim;
         info[0] = (int64_t)m.SNRdB.size(); info[1] = (int64_t)m.Nframes; info[2] = m.Nfers; info[3] = m.get_codeword_length();
         info[4] = m.get_dataword_length(); info[5] = m.max_iter; info[6] = m.zero_codeword ? 1 : 0; info[7] = m.batch_frames;
         limits[0] = m.ber_min; limits[1] = m.fer_min;

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * or_sim.c -- ORACLE (test infrastructure): the Monte-Carlo frame loop of
  * LDPC_BER_Sim::sim_snr_point / run (src/LDPC_BER_Sim.cpp:121-155,246-311), frame by frame like
@@ -188,4 +189,32 @@ int or_sim_channel_cells(const or_codec *c, double snr_db, double rate, uint64_t
         cha[j] = C.cha[j]; msg[j] = C.msg[j]; neg[j] = C.neg[j]; cha_m[j] = C.cha_m[j]; msg_m[j] = C.msg_m[j];
     }
     return C.n_cells;
+}
+
+/* [BP] front end: BPSK over AWGN in double precision, Philox-addressed per (seed, stream = SNR index, frame, bit pair), one
+ * Box-Muller pair per block (the specification of lut_ldpc_amd/csrc/host/ber_sim_driver.hpp: awgn_llr_frames; restates
+ * src/LDPC_BER_Sim.cpp:270-283 with this build's RNG -- the IT++ RNG is absent, PARITY UNPINNED).  llr[B][N], uncoded[B]. */
+void or_sim_awgn_llr(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const uint8_t *codewords, double *llr, int *uncoded)
+{
+    const double sigma = sqrt(N0 / 2), two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < B; i++) {
+        const uint64_t frame = frame0 + (uint64_t)i;
+        int unc = 0;
+        for (int p = 0; p < (N + 1) / 2; p++) {
+            px_out o = philox4x32_10((uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)p, stream | 0x40000000u, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const double u1 = ((double)((((uint64_t)o.w[0] << 32) | o.w[1]) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+            const double u2 = (double)((((uint64_t)o.w[2] << 32) | o.w[3]) >> 11) * (1.0 / 9007199254740992.0);
+            const double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincos(two_pi * u2, &sn, &cs);         /* one libm entry point for both, as in the product */
+            const double z[2] = { rad * cs, rad * sn };
+            for (int k = 0; k < 2 && 2 * p + k < N; k++) {
+                const int v = 2 * p + k, bit = codewords ? codewords[(size_t)i * N + v] : 0;
+                const double x = (bit ? -1.0 : 1.0) + sigma * z[k];
+                llr[(size_t)i * N + v] = 4.0 * x / N0;
+                unc += ((x < 0) ? 1 : 0) != bit;
+            }
+        }
+        uncoded[i] = unc;
+    }
 }

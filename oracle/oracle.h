@@ -201,6 +201,18 @@ void     or_flat_free(or_flat *F);
 void     or_flat_decode_batch_u8(const or_flat *F, const uint8_t *cha, const uint8_t *msg0, int B,
                                  uint8_t *out_bits, int32_t *out_iters, int n_threads);
 
+/* [BP] comparison decoder (or_bp.c): the specification of include/lut_ldpc_bp.h on the CPU.  PARITY UNPINNED (IT++ fork absent). */
+typedef struct or_bp or_bp;
+or_bp *or_bp_new(const or_code *code, int d1, int d2, int d3, int d4);
+void   or_bp_free(or_bp *b);
+void   or_bp_set_exit_conditions(or_bp *b, int max_iters, int psc, int pisc);
+int    or_bp_table(const or_bp *b, int *out);
+int    or_bp_to_qllr(const or_bp *b, double l);
+void   or_bp_decode_qllr_batch(const or_bp *b, const int *qllr, int B, uint8_t *out_bits, int32_t *out_iters, int *out_qllr);
+void   or_bp_decode_llr_batch(const or_bp *b, const double *llr, int B, uint8_t *out_bits, int32_t *out_iters, int *out_qllr);
+
+void   or_sim_awgn_llr(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const uint8_t *codewords, double *llr, int *uncoded);
+
 void or_free(void *p);
 
 #ifdef __cplusplus

@@ -53,6 +53,13 @@ def lib() -> C.CDLL:
             "or_codec_set_exit_conditions": (None, [vp, C.c_int, C.c_int, C.c_int]),
             "or_codec_lut_decode_batch_u8": (None, [vp, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int32)]),
             "or_codec_decode_llr": (C.c_int, [vp, dp, u8p, ip, ip]),
+            "or_sim_awgn_llr": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_double, u8p, dp, ip]),
+            "or_bp_new": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+            "or_bp_free": (None, [vp]),
+            "or_bp_set_exit_conditions": (None, [vp, C.c_int, C.c_int, C.c_int]),
+            "or_bp_table": (C.c_int, [vp, ip]),
+            "or_bp_decode_qllr_batch": (None, [vp, ip, C.c_int, u8p, C.POINTER(C.c_int32), ip]),
+            "or_bp_decode_llr_batch": (None, [vp, dp, C.c_int, u8p, C.POINTER(C.c_int32), ip]),
             "or_flat_new": (vp, [vp]),
             "or_flat_free": (None, [vp]),
             "or_flat_decode_batch_u8": (None, [vp, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int32), C.c_int]),
@@ -318,3 +325,49 @@ def de_threshold(dl, lam, dr, rho, qbits_cha=4, qbits_msg=4, maxiter_de=2000, mi
                                    maxiter_de, int(min_lut), tree_mode.encode(), strategy.encode(), thr_min, thr_prec,
                                    pe_max, maxiter_bisec, max_ni_de_iters, llr_max, nq_fine, C.byref(thr))
     return thr.value, it
+
+
+class BP:
+    """[BP] comparison decoder of the oracle (or_bp.c): the specification of include/lut_ldpc_bp.h on the CPU.  PARITY
+    UNPINNED against the reference's forked IT++ (absent)."""
+
+    def __init__(self, code: "Code", d1=12, d2=300, d3=7, d4=28):
+        self.code = code
+        self._h = lib().or_bp_new(code._h, d1, d2, d3, d4)
+        self.d2 = d2
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().or_bp_free(self._h)
+            self._h = None
+
+    def set_exit_conditions(self, max_iters, psc=True, pisc=False):
+        lib().or_bp_set_exit_conditions(self._h, int(max_iters), int(psc), int(pisc))
+
+    def table(self) -> np.ndarray:
+        out = np.zeros(max(self.d2, 1), np.int32)
+        n = lib().or_bp_table(self._h, _ip(out))
+        return out[:n]
+
+    def _decode(self, fn, a, ptr):
+        B, N = a.shape
+        bits, iters, q = np.zeros((B, N), np.uint8), np.zeros(B, np.int32), np.zeros((B, N), np.int32)
+        fn(self._h, ptr, B, _u8p(bits), iters.ctypes.data_as(C.POINTER(C.c_int32)), _ip(q))
+        return bits, iters, q
+
+    def decode_llr_batch(self, llr):
+        a = np.ascontiguousarray(llr, np.float64)
+        return self._decode(lib().or_bp_decode_llr_batch, a, a.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def decode_qllr_batch(self, qllr):
+        a = np.ascontiguousarray(qllr, np.int32)
+        return self._decode(lib().or_bp_decode_qllr_batch, a, _ip(a))
+
+
+def awgn_llr(seed, stream, frame0, B, N, N0, codewords=None):
+    """BPSK / AWGN LLRs of frames frame0..frame0+B-1 ([BP] front end, or_sim.c): (llr [B, N] float64, uncoded errors [B])."""
+    llr, unc = np.zeros((B, N), np.float64), np.zeros(B, np.int32)
+    cw = None if codewords is None else np.ascontiguousarray(codewords, np.uint8)
+    lib().or_sim_awgn_llr(int(seed), int(stream), int(frame0), int(B), int(N), float(N0), _u8p(cw) if cw is not None else None,
+                          llr.ctypes.data_as(C.POINTER(C.c_double)), _ip(unc))
+    return llr, unc

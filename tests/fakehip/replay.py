@@ -91,6 +91,16 @@ def scenarios(which):
         run("c5_chklut", 20, 4.2, {}, [(True, True)])
         run("dvbs2_q4_i6", 1030, 1.0, {}, [(True, True), (False, False)], repeats=3, with_oracle=False)
         assert fake.fakehip_captures() > 0 and fake.fakehip_graph_launches() > 0 and fake.fakehip_launches_of(b"pass_fused_kernel") > 0
+        # the [BP] comparison decoder: growing and shrinking batches, both entry points
+        from oracle import oracle as orc
+        code = orc.Code(ROOT / "data" / "codes" / "rate0.50_dv02-17_dc08-09_lut_q4_N500.alist")
+        bp = L.BPDecoder(code.nvar, code.nchk, code.dv, code.dc, code.cn_msg_idx, device=0)
+        for B in (3, 700, 40):
+            bp.set_exit_conditions(5, True, True)
+            bp.decode_llr_batch(np.ones((B, code.nvar)), want_qllr=True)
+            bp.decode_qllr_batch(np.ones((B, code.nvar), np.int32))
+        bp.close()
+        assert fake.fakehip_launches_of(b"bp_cn_kernel") > 0
         done.append("quick")
     if which in ("all", "parity"):
         # tests/test_decode_parity_gpu.py, in collection order: the 27 oracle-parity cases, then the knob variants

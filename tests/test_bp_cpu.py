@@ -1,0 +1,72 @@
+"""[BP] comparison decoder, CPU side: the oracle's statement of the specification in include/lut_ldpc_bp.h (table, quantiser,
+decoding behaviour) and the product's host-only handle (same table from the same formula, refusal to decode without a device).
+PARITY UNPINNED against the reference's forked IT++ (absent from the reference tree): these tests pin the two implementations
+of this repository to each other and to the published properties of the algorithm."""
+import numpy as np
+import pytest
+
+import lut_ldpc_amd as L
+from helpers import CODES
+from oracle import oracle as orc
+
+
+def _llr(code, B, snr_db, seed, rate=0.5):
+    rng = np.random.default_rng(seed)
+    N0 = 10 ** (-snr_db / 10) / rate
+    return 4 * (1.0 + rng.normal(0.0, np.sqrt(N0 / 2), (B, code.nvar))) / N0
+
+
+def test_logexp_table_and_quantiser():
+    code = orc.Code(CODES / "rate0.50_dv03_dc06_N1000.alist")
+    bp = orc.BP(code, 12, 300, 7, 28)
+    t = bp.table()
+    assert len(t) == 300 and t[0] == round(np.log(2.0) * 4096) and (np.diff(t) <= 0).all() and t[-1] == 0
+    # the table the product builds on the host (no device) from the same formula
+    dec = L.BPDecoder(code.nvar, code.nchk, code.dv, code.dc, code.cn_msg_idx, 12, 300, 7, 28, device=-1)
+    assert (dec.logexp_table() == t).all()
+    with pytest.raises(L.LutLdpcError):
+        dec.decode_llr_batch(np.zeros((1, code.nvar)))
+    dec.close()
+    with pytest.raises(L.LutLdpcError):                       # itpp::LDPC_Code::bp_decode stops on a check of degree 1
+        L.BPDecoder(2, 2, [1, 1], [1, 1], [0, 1], device=-1)
+
+
+@pytest.mark.parametrize("d2", [300, 0])
+def test_oracle_bp_corrects_errors_and_reports_like_itpp(d2):
+    code = orc.Code(CODES / "rate0.50_dv03_dc06_N1000.alist")
+    bp = orc.BP(code, 12, d2, 7, 28)
+    llr = _llr(code, 12, 2.4, seed=3)
+    assert ((llr < 0).sum(1) > 20).all()                     # the channel alone leaves dozens of bit errors per frame
+    bp.set_exit_conditions(40, True, True)
+    bits, it, q = bp.decode_llr_batch(llr)
+    assert (it > 0).all() and (it < 40).all() and not bits.any() and (q >= 0).all()
+    bp.set_exit_conditions(40, False, False)                  # without the syndrome check success is never reported
+    bits2, it2, _ = bp.decode_llr_batch(llr)
+    assert (it2 == -40).all() and not bits2.any()
+    clean = np.full((2, code.nvar), 9.0)
+    bp.set_exit_conditions(40, True, True)
+    _, it3, q3 = bp.decode_llr_batch(clean)
+    assert (it3 == 0).all() and (q3 == round(9.0 * 4096)).all()   # pisc: output = input
+    # frames are independent
+    a = bp.decode_llr_batch(llr[:5])
+    assert (a[0] == bits[:5]).all() and (a[1] == it[:5]).all()
+
+
+def test_host_awgn_front_end_equals_oracle_and_is_gaussian():
+    """The [BP] path's noise: product (C++ host) and oracle (C) give the same doubles for the same Philox address, any split
+    of the frame range gives the same frames, and the samples have the moments of 4 x / N0."""
+    from lut_ldpc_amd.bp import awgn_llr
+    N, N0 = 1001, 0.8
+    a, ua = awgn_llr(5, 3, 10, 40, N, N0)
+    b, ub = orc.awgn_llr(5, 3, 10, 40, N, N0)
+    assert (a == b).all() and (ua == ub).all()
+    c, _ = awgn_llr(5, 3, 30, 20, N, N0)
+    assert (c == a[20:]).all()
+    cw = (np.arange(40 * N).reshape(40, N) % 3 == 0).astype(np.uint8)
+    d, ud = awgn_llr(5, 3, 10, 40, N, N0, cw)
+    e, ue = orc.awgn_llr(5, 3, 10, 40, N, N0, cw)
+    assert (d == e).all() and (ud == ue).all()
+    assert (np.sign(d - 4 * (1 - 2.0 * cw) / N0) == np.sign(a - 4 / N0)).all()      # same noise, other signal
+    z = (a * N0 / 4 - 1.0) / np.sqrt(N0 / 2)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 3).mean()) < 0.05 and abs((z ** 4).mean() - 3) < 0.15
+    assert (ua == (a < 0).sum(1)).all()
