@@ -159,7 +159,7 @@ struct lutldpc_decoder {
     int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, (cn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
     int use_fast = 1;
     int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
-    int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (needs G >= 2)
+    int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (one frame group: second half empty)
     bool skew_ok = false;       // every class of every set has a case in the fused kernel
     int fused_bucket_id = 0;    // degree bucket of the fused kernel (kernels_fast.hpp: kFusedVnDeg / kFusedCnDeg)
     // launch plan of the skewed pipeline for one (frame groups, psc, max_iters): the roles of every launch in DEVICE memory
@@ -1063,7 +1063,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
         LAUNCH_CHECK();
     }
-    const bool skewed = d->skew && d->skew_ok && G >= 2;
+    const bool skewed = d->skew && d->skew_ok;      // (a single frame group runs the same launches with an empty second half)
     if (skewed && (rc = iterate_skewed(d, B, Bpad, G))) return rc;
     for (int ii = 0; ii < I && !skewed; ii++) {   // :301-338
         const int set = d->iter_set[(size_t)ii];
