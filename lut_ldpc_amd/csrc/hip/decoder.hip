@@ -102,6 +102,7 @@ struct lutldpc_decoder {
     // per variable class the dense table / count of the nodes NOT updated inside the check pass
     std::vector<int> chain_idx_off, vn_red_off, vn_red_n;
     int chain_vclass = -1, n_chain_nodes = 0, use_chain = 1;
+    std::vector<int> cn_npw_class;          // checks per wave of each check class (chain-rich classes of wide checks get at least 4)
     // ---- device
     int device = -1;
     hipStream_t stream = nullptr;
@@ -157,6 +158,7 @@ struct lutldpc_decoder {
     static constexpr int work_shift = 0;
     int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, (vn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
     int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, (cn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
+    int npw_cn_class(size_t ci) const { return ci < cn_npw_class.size() && cn_npw_class[ci] > 0 ? cn_npw_class[ci] : npw_cn(cclass[ci].deg); }
     int use_fast = 1;
     int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
     int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (one frame group: second half empty)
@@ -284,6 +286,20 @@ void build_fast_index(lutldpc_decoder *d) {
         for (size_t j = 0; j < d->cclass[ci].nodes.size(); j++) { cls_of[(size_t)d->cclass[ci].nodes[j]] = (int)ci; pos_of[(size_t)d->cclass[ci].nodes[j]] = (int)j; }
     std::vector<int> back((size_t)d->nchk, 0), fwd((size_t)d->nchk, 0);
     std::vector<char> internal((size_t)d->nvar, 0);
+    // checks per wave: a class of wide checks whose members are mostly linked by degree-2 nodes (the zigzag of a dual-diagonal
+    // code) gets at least four checks per wave, so that three of four links fall inside a wave
+    d->cn_npw_class.assign(d->cclass.size(), 0);
+    if (d->use_chain && d->min_lut) {
+        std::vector<int> cand(d->cclass.size(), 0);
+        for (int v = 0; v < d->nvar; v++) {
+            if (d->dv[(size_t)v] != 2) continue;
+            const int e0 = d->vn_ptr[(size_t)v], c1 = edge_chk[(size_t)e0], c2 = edge_chk[(size_t)e0 + 1];
+            if (c1 < 0 || c2 < 0 || c1 == c2 || cls_of[(size_t)c1] != cls_of[(size_t)c2]) continue;
+            if (std::abs(pos_of[(size_t)c1] - pos_of[(size_t)c2]) == 1) cand[(size_t)cls_of[(size_t)c1]]++;
+        }
+        for (size_t ci = 0; ci < d->cclass.size(); ci++)
+            if (2 * cand[ci] >= (int)d->cclass[ci].nodes.size() && d->nodes_per_wave_cn <= 0) d->cn_npw_class[ci] = std::max(4, d->npw_cn(d->cclass[ci].deg));
+    }
     if (d->use_chain && d->min_lut)
         for (int v = 0; v < d->nvar; v++) {
             if (d->dv[(size_t)v] != 2) continue;
@@ -291,8 +307,8 @@ void build_fast_index(lutldpc_decoder *d) {
             int c1 = edge_chk[(size_t)e0], c2 = edge_chk[(size_t)e0 + 1];
             if (c1 < 0 || c2 < 0 || c1 == c2 || cls_of[(size_t)c1] != cls_of[(size_t)c2]) continue;
             if (pos_of[(size_t)c1] > pos_of[(size_t)c2]) std::swap(c1, c2);
-            const int deg = d->cclass[(size_t)cls_of[(size_t)c1]].deg, npw = d->npw_cn(deg);
-            if (deg < 2 || deg > kFusedCnDeg[0] || pos_of[(size_t)c2] != pos_of[(size_t)c1] + 1 || pos_of[(size_t)c1] / npw != pos_of[(size_t)c2] / npw) continue;
+            const int deg = d->cclass[(size_t)cls_of[(size_t)c1]].deg, npw = d->npw_cn_class((size_t)cls_of[(size_t)c1]);
+            if (deg < 2 || deg > kFusedCnDeg[kFusedBuckets - 1] || pos_of[(size_t)c2] != pos_of[(size_t)c1] + 1 || pos_of[(size_t)c1] / npw != pos_of[(size_t)c2] / npw) continue;
             if (fwd[(size_t)c1] || back[(size_t)c2]) continue;
             fwd[(size_t)c1] = v + 1; back[(size_t)c2] = v + 1; internal[(size_t)v] = 1;
         }
@@ -750,10 +766,10 @@ bool late_hard_active(const lutldpc_decoder *d, bool skewed, bool *chain_skip) {
     return true;
 }
 
-// chain fusion applies to a check pass that is followed by a variable pass (not the last iteration), on the first
-// degree bucket, when the degree-2 class has the compile-time kernel (its root table is staged)
+// chain fusion applies to a check pass that is followed by a variable pass (not the last iteration) when the degree-2
+// class has the compile-time kernel (its root table is staged)
 bool chain_active(const lutldpc_decoder *d, int set) {
-    if (!d->use_chain || d->fused_bucket_id != 0 || d->chain_vclass < 0 || d->n_chain_nodes == 0) return false;
+    if (!d->use_chain || d->chain_vclass < 0 || d->n_chain_nodes == 0) return false;
     const FastClassPlan &f = d->var_fast[(size_t)set][(size_t)d->chain_vclass];
     return f.ok && f.P.n_tables == 1 && f.P.tab_len[0] <= 1024;
 }
@@ -778,7 +794,7 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
                 R.chain.sbit_out = __builtin_ctz((unsigned)(d->Nq_Msg[(size_t)(ii + 1)] / 2) | 0x100u);
             }
         }
-        const int npw = d->npw_cn(d->cclass[i].deg);
+        const int npw = d->npw_cn_class(i);
         R.kind = 0; R.deg = d->cclass[i].deg; R.g0 = h.g0; R.G = h.G;
         R.n_nodes = (int)d->cclass[i].nodes.size(); R.nodes_per_wave = npw;
         R.waves_per_group = (R.n_nodes + npw - 1) / npw;
@@ -857,7 +873,6 @@ int validate_fused(const lutldpc_decoder *d, const FusedParams &FP, const std::v
             if (R.idx_off < 0 || (size_t)R.idx_off + (size_t)R.n_nodes * (size_t)R.deg > idx_n) return bad(r, "edge table");
             if (!is_pow2(R.nz) || R.nz > 64) return bad(r, "nz");
             if (R.chain.on || R.chain.hard) {
-                if (d->fused_bucket_id != 0) return bad(r, "chain fusion outside the first bucket");
                 if (R.chain.idx_off < 0 || (size_t)R.chain.idx_off + 2 * (size_t)R.n_nodes > idx_n) return bad(r, "chain link table");
                 if (R.chain.on && (R.chain.tab_off < 0 || R.chain.tab_len < 4 || R.chain.tab_len > 1024 || (size_t)R.chain.tab_off + (size_t)R.chain.tab_len > tab_n)) return bad(r, "chain table");
                 if (R.chain.on && R.chain.check && (R.chain.vfail_off_w < 0 || (size_t)R.chain.vfail_off_w + (size_t)kVfailSlots * (size_t)R.vfail_stride_w > vfail_w)) return bad(r, "chain flag buffer");
@@ -1212,7 +1227,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"chain_nodes\":" << ((d->use_chain && d->fused_bucket_id == 0) ? d->n_chain_nodes : 0) << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 

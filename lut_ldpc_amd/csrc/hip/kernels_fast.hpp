@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
 // an iteration out of phase (decoder.hip: decode_tiles_skewed) and every launch mixes both kinds of
 // work on every CU: blocks are handed to roles (degree class x pass kind x half) through an
 // interleaved item table, each block stays homogeneous (one role) so its tables sit at LDS offset 0.
+// occupancy window of the first bucket's fused kernel (build-time knobs for tools/ab_variants.sh; 7..8 measured best)
+#ifndef LUTLDPC_B0_WAVES_MIN
+#define LUTLDPC_B0_WAVES_MIN 7
+#endif
+#ifndef LUTLDPC_B0_WAVES_MAX
+#define LUTLDPC_B0_WAVES_MAX 8
+#endif
 constexpr int kFusedMaxRoles = 10;
 constexpr int kFusedMaxTables = 20;
 // Degree buckets of the fused kernel.  Its register count is the maximum over all the cases it contains
@@ -553,7 +560,7 @@ __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, 
 // for the whole decode: the role is picked with a wave-uniform run-time index, its fields come in through scalar
 // loads as they are needed).  The kernel-argument segment stays a handful of pointers.
 template <int PACK, bool CHECK, int BUCKET>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? 7 : BUCKET == 1 ? 4 : 3, 8))) void pass_fused_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? LUTLDPC_B0_WAVES_MIN : BUCKET == 1 ? 4 : 3, BUCKET == 0 ? LUTLDPC_B0_WAVES_MAX : 8))) void pass_fused_kernel(
     const RoleParams *__restrict__ roles, const int2 *__restrict__ items, int prio, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)
 {
@@ -566,8 +573,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0
         if (P.deg >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     }
     if (P.kind == 0) {
-        // chain fusion exists in the small-degree bucket only (dual-diagonal codes: DVB-S2, IRA)
-        if (BUCKET == 0 && (P.chain.on || P.chain.hard)) fused_cn_switch<PACK, BUCKET == 0>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
+        // chain fusion (dual-diagonal codes: DVB-S2 at every rate, IRA): every bucket has the chained check bodies
+        if (P.chain.on || P.chain.hard) fused_cn_switch<PACK, true>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
         else fused_cn_switch<PACK, false>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
     }
     else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);

@@ -98,3 +98,41 @@ def compare(cd, dec, cha, msg, psc, pisc, max_iters=None):
     bad = np.argwhere(want_bits != got_bits)
     assert bad.size == 0, f"{len(bad)} bit mismatches, first at frame/bit {bad[:4].tolist()}"
     return want_it
+
+
+def write_ira_alist(path, K, M, dv_info, seed=0):
+    """A dual-diagonal (IRA / DVB-S2 style) code for the tests: K information nodes of degree dv_info spread evenly over M checks
+    plus M parity nodes of degree 2 in a (tail-biting) zigzag, parity node j joining checks j and j+1.  Check degree
+    K*dv_info/M + 2.  Returns (N, M)."""
+    rng = np.random.default_rng(seed)
+    assert (K * dv_info) % M == 0
+    per = K * dv_info // M
+    sockets = np.repeat(np.arange(M), per)
+    rng.shuffle(sockets)
+    cols = sockets.reshape(K, dv_info).copy()
+    for _ in range(100):                                   # repair columns that got the same check twice by swapping sockets
+        bad = [v for v in range(K) if len(set(cols[v])) < dv_info]
+        if not bad:
+            break
+        for v in bad:
+            for k in range(1, dv_info):
+                if cols[v][k] in cols[v][:k]:
+                    w = int(rng.integers(K))
+                    j = int(rng.integers(dv_info))
+                    if cols[w][j] not in cols[v] and cols[v][k] not in cols[w]:
+                        cols[v][k], cols[w][j] = cols[w][j], cols[v][k]
+    assert all(len(set(c)) == dv_info for c in cols)
+    col_rows = [sorted(int(r) for r in c) for c in cols] + [sorted({j, (j + 1) % M}) for j in range(M)]
+    N = K + M
+    row_cols = [[] for _ in range(M)]
+    for v, rows in enumerate(col_rows):
+        for r in rows:
+            row_cols[r].append(v)
+    with open(path, "w") as f:
+        f.write(f"{N} {M}\n{max(len(c) for c in col_rows)} {max(len(r) for r in row_cols)}\n")
+        f.write(" ".join(str(len(c)) for c in col_rows) + "\n" + " ".join(str(len(r)) for r in row_cols) + "\n")
+        for c in col_rows:
+            f.write(" ".join(str(r + 1) for r in c) + "\n")
+        for r in row_cols:
+            f.write(" ".join(str(v + 1) for v in sorted(r)) + "\n")
+    return N, M

@@ -148,3 +148,29 @@ def test_fewer_iterations_than_designed_is_rejected_unless_decision_set():
     with pytest.raises(L.LutLdpcError):
         dec.set_exit_conditions(4)
     dec.close()
+
+
+@pytest.mark.parametrize("K,M,dv,bucket", [(1600, 400, 3, 1), (3600, 400, 3, 2), (840, 420, 3, 0)])
+def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket):
+    """Dual-diagonal codes with check degrees 14 (middle bucket), 29 (widest) and 8 (first): most zigzag nodes are updated
+    inside the check pass in every bucket, one frame group and several, fixed work and early termination."""
+    from helpers import write_ira_alist
+    from oracle import oracle as orc
+    N, _ = write_ira_alist(tmp_path / "ira.alist", K, M, dv, seed=K)
+    code = orc.Code(tmp_path / "ira.alist")
+    cd = orc.Codec(code, skip_rank=True)
+    cd.set_rank(M)
+    cd.rate = 1.0 - M / N
+    sig = {1: 0.52, 2: 0.40, 0: 0.62}[bucket]
+    cd.design_luts(sigma2=sig ** 2, max_iters=10, nq_msg=np.full(10, 16, np.int32), nq_cha=16)
+    dec = product_decoder(cd)
+    desc = dec.describe()
+    assert desc["fused_bucket"] == bucket and desc["skewed_pipeline"] == 1, desc
+    assert desc["chain_nodes"] >= M // 2, desc                    # at least every second zigzag node (3 of 4 with four checks per wave)
+    snr = -10 * np.log10(2 * cd.rate * sig * sig) + 0.3
+    for B in (700, 200):
+        cha, msg, _ = awgn_labels(cd, B, snr, seed=B)
+        it = _compare(cd, dec, cha, msg, True, True)
+        assert (it > 0).sum() > 0
+        _compare(cd, dec, cha, msg, False, False)
+    dec.close()
