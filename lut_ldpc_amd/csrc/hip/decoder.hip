@@ -148,6 +148,8 @@ struct lutldpc_decoder {
     int late_hard = 1;
     DevBuf<uint8_t> d_chain_internal;      // 1 = variable node updated inside the check pass (build_fast_index)
     std::vector<uint8_t> chain_internal;
+    DevBuf<int32_t> d_edge_vn;              // variable node of every edge (chain_hard_kernel)
+    std::vector<int32_t> edge_vn;
     int sweep_reverse = 0;      // LUTLDPC_REVERSE: alternate the sweep direction over the frame groups between launches
     int use_graph = 1;          // replay repeated decodes as one hipGraph launch (decode_tiles)
     struct GraphSlot { int seen = 0; hipGraphExec_t exec = nullptr; };
@@ -543,6 +545,9 @@ int upload_static(lutldpc_decoder *d) {
     HIP_TRY(d->d_cn_list.upload(d->cn_list));
     HIP_TRY(d->d_fast_idx.upload(d->fast_idx));
     HIP_TRY(d->d_chain_internal.upload(d->chain_internal));
+    d->edge_vn.resize((size_t)d->E);
+    for (int v = 0; v < d->nvar; v++) for (int e = d->vn_ptr[(size_t)v]; e < d->vn_ptr[(size_t)v + 1]; e++) d->edge_vn[(size_t)e] = v;
+    HIP_TRY(d->d_edge_vn.upload(d->edge_vn));
     HIP_TRY(d->d_ops.upload(d->all_ops));
     {   // pad the table blob so that dword staging never reads past the end
         std::vector<uint8_t> t = d->all_tables;
@@ -778,7 +783,9 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
     const int I = d->max_iters, nz = d->Nq_Msg[(size_t)ii] / 2;
     const int buf_w = kVfailSlots * d->Bcap / 4;                      // words per flag buffer
     const bool on = ii != I - 1 && chain_active(d, d->iter_set[(size_t)ii]);
-    const bool hard = d->psc && ii >= 1 && chain_active(d, d->iter_set[(size_t)(ii - 1)]);
+    // decided bits of the nodes updated here: stored by the check pass that reads their messages, unless they are recovered at
+    // the end with everything else (late_hard_active + chain_hard_kernel)
+    const bool hard = d->psc && ii >= 1 && chain_active(d, d->iter_set[(size_t)(ii - 1)]) && !late_hard_active(d, true, nullptr);
     for (size_t i = 0; i < d->cclass.size(); i++) {
         RoleParams R{};
         R.vfail_off_w = (ii & 1) * buf_w;                             // parity flags: this iteration's exit test
@@ -920,6 +927,28 @@ int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan,
     return LUTLDPC_OK;
 }
 
+// Decided bits of the frames that left through the exit test, read off their frozen messages (hard_from_frozen_kernel) and, for
+// the nodes updated inside the check pass, off the parity equations (chain_hard_kernel): groups g0 .. g0+G-1; ctl: a compaction
+// check point's control words (the kernels return when it does not permute) or NULL at the end of the decode.
+int launch_late_hard(lutldpc_decoder *d, bool skewed, int g0, int G, const int32_t *ctl) {
+    bool chain_skip = false;
+    if (!late_hard_active(d, skewed, &chain_skip) || G <= 0) return LUTLDPC_OK;
+    const unsigned gx = ctl ? 1024u : 2048u;
+    PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(gx, (unsigned)((d->nvar + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
+                                        reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, d->nvar, d->E,
+                                        d->Nq_Msg[0] / 2, g0, ctl));
+    if (chain_skip)
+        for (size_t i = 0; i < d->cclass.size(); i++) {
+            if (d->chain_idx_off[i] < 0) continue;
+            const int n = (int)d->cclass[i].nodes.size(), npw = d->npw_cn_class(i), runs = (n + npw - 1) / npw;
+            PACK_DISPATCH(d, hipLaunchKernelGGL(chain_hard_kernel<PK>, dim3(std::min<unsigned>(512u, (unsigned)((runs + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+                                                reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_fast_idx.p + d->cn_idx_off[i], d->d_fast_idx.p + d->chain_idx_off[i],
+                                                d->d_edge_vn.p, n, d->cclass[i].deg, npw, d->nvar, g0, ctl));
+        }
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
 // kernels_compact.hpp: a check point of one half right after its exit test of iteration ii -- the plan kernel decides on the
 // device whether permuting the slots (active frames first) pays; if not, the row kernels return at once
 constexpr unsigned kPermuteBlocks = 1024;
@@ -943,12 +972,9 @@ int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     int32_t *ctl = d->d_ctl.p + 4 * hf;
     hipLaunchKernelGGL(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
                        d->compact_margin > 0 ? d->compact_min_share : 0.0f);
-    bool chain_skip = false;
-    const bool late = late_hard_active(d, true, &chain_skip);
-    if (late)      // the decided bits of the frames that left since the last permutation, before their messages are dropped
-        PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((d->nvar + 3) / 4)), (unsigned)h.G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
-                                            reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, d->nvar, d->E,
-                                            d->Nq_Msg[0] / 2, h.g0, ctl));
+    const bool late = late_hard_active(d, true, nullptr);
+    // the decided bits of the frames that left since the last permutation, before their messages are dropped
+    if (int rc = launch_late_hard(d, true, h.g0, h.G, ctl)) return rc;
     hipLaunchKernelGGL(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
                        d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, late ? 1 : 0);
     const size_t lds = permute_lds_bytes(d, h.G);
@@ -1096,14 +1122,8 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         }
     }
     {   // decided bits of the frames that left through the exit test, from their frozen messages (see late_hard_active)
-        bool chain_skip = false;
-        if (late_hard_active(d, skewed, &chain_skip)) {
-            Timed t(d, LUTLDPC_K_LAYOUT);
-            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(2048u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
-                                                reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, N, E, d->Nq_Msg[0] / 2,
-                                                0, (const int32_t *)nullptr));
-            LAUNCH_CHECK();
-        }
+        Timed t(d, LUTLDPC_K_LAYOUT);
+        if ((rc = launch_late_hard(d, skewed, 0, G, nullptr))) return rc;
     }
     // :340-349
     if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], d->dec_jit.empty() ? nullptr : &d->dec_jit[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
@@ -1345,7 +1365,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (auto &e : d->ev_live) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : d->ev_pool) (void)hipEventDestroy(e);
-        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release(); d->d_chain_internal.release();
+        d->d_vn_ptr.release(); d->d_cn_ptr.release(); d->d_cn_idx.release(); d->d_cn_vn.release(); d->d_vn_list.release(); d->d_cn_list.release(); d->d_fast_idx.release(); d->d_chain_internal.release(); d->d_edge_vn.release();
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();

@@ -437,6 +437,48 @@ __global__ __launch_bounds__(256) void hard_from_frozen_kernel(const uint8_t *__
     }
 }
 
+// Decided bits of the variable nodes that are updated INSIDE the check pass (chain fusion), for the frames that left through
+// the exit test: their edges hold new variable-to-check messages, not the frozen check-to-variable ones, so their bits
+// cannot be read off them -- but a frame that passed the test satisfies every check, and each such node is the only unknown
+// of one check once the run is walked in order: bit(forward node of check j) = XOR of the bits of all other nodes of check j
+// (the accumulator of a dual-diagonal code, read backwards).  One wave per run of `npw` checks of a class (the same runs as
+// the check pass); the bit row of the node shared with the next check travels in a register.  Runs after
+// hard_from_frozen_kernel (which supplies every other node), with the same frame mask; replaces the per-pass stores.
+//   edges: dense [n_nodes][deg] edge ids of the class, links: [n_nodes][2] = {back node + 1, forward node + 1},
+//   edge_vn[e] = variable node of edge e.
+template <int PACK>
+__global__ __launch_bounds__(256) void chain_hard_kernel(uint8_t *__restrict__ hard, const uint32_t *__restrict__ state_w, const int32_t *__restrict__ edges,
+                                                         const int32_t *__restrict__ links, const int32_t *__restrict__ edge_vn, int n_nodes, int deg, int npw, int N,
+                                                         int g0, const int32_t *__restrict__ ctl)
+{
+    if (ctl && ctl[1]) return;
+    const int lane = threadIdx.x & 63, g = g0 + blockIdx.y;
+    uint32_t m[PACK], any = 0;
+#pragma unroll
+    for (int h = 0; h < PACK; h++) { m[h] = swar_zero_mask(state_w[frame_word<PACK>(g, lane, h)] ^ (ST_DONE_PSC * 0x01010101u)); any |= m[h]; }
+    if (wave_all_zero(any)) return;
+    const uint32_t smask = pack_masks<PACK>(m);
+    const int runs = (n_nodes + npw - 1) / npw;
+    const int w0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), step = (int)gridDim.x * 4;
+    uint8_t *hb = hard + (size_t)g * (size_t)N * kRowBytes + lane * 4;
+    for (int r = w0; r < runs; r += step) {
+        const int j0 = r * npw, j1 = min(j0 + npw, n_nodes);
+        uint32_t carry = 0;                                   // bit row of the node shared with the previous check of the run
+        for (int j = j0; j < j1; j++) {
+            const int lb = links[2 * (size_t)j], lf = links[2 * (size_t)j + 1];
+            if (!lf) continue;                                // no node of this check is updated inside the check pass towards the next one
+            uint32_t acc = lb ? carry : 0u;                   // (lb != 0: the back node was computed one step ago, same run by construction)
+            for (int k = 0; k < deg; k++) {
+                const int v = edge_vn[edges[(size_t)j * deg + k]];
+                if (v == lf - 1 || (lb && v == lb - 1)) continue;
+                acc ^= *reinterpret_cast<const uint32_t *>(hb + (size_t)v * kRowBytes);
+            }
+            store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hb + (size_t)(lf - 1) * kRowBytes), acc, smask);
+            carry = acc;
+        }
+    }
+}
+
 // parity of every check over the hard decisions (src/LDPC_Code_LUT.cpp:455-469): vfail |= syndrome.
 // cn_vnf[k] = variable node of check-edge k, bit 31 set on the last edge of its check; padded with 8
 // zero entries.  A wave walks the run of edges of its checks eight at a time: ONE vector load fetches
