@@ -449,7 +449,7 @@ __device__ __forceinline__ void vn_balanced_body(
                     if (CHECK) {
                         // sign of a label = bit sbit (nz = 1 << sbit): negative (bit 1 decided) <=> bit clear;
                         // the node fails the unanimity test when any two outgoing signs differ
-                        hardw = lshl_or(((r0 >> sbit) & 1u) ^ 1u, s, hardw);
+                        if (P.write_hard) hardw = lshl_or(((r0 >> sbit) & 1u) ^ 1u, s, hardw);      // (wave-uniform; off when the bits are recovered at the end)
                         failw = lshl_or((diff >> sbit) & 1u, s, failw);
                     }
                 }
