@@ -4,14 +4,17 @@ import sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
 import lut_ldpc_amd as L
 from lut_ldpc_amd.bp import awgn_llr
-from oracle import oracle as orc
 
 for alist, B, it in [("rate0.50_irreg_dvbs2_N64800", 2048, 30), ("rate0.50_dv03_dc06_N10000", 8192, 30), ("rate0.50_dv03_dc06_N1000", 32768, 30)]:
-    code = orc.Code(ROOT / "data" / "codes" / f"{alist}.alist")
-    dec = L.BPDecoder(code.nvar, code.nchk, code.dv, code.dc, code.cn_msg_idx, device=0)
+    cd = L.Codec(ROOT / "data" / "codes" / f"{alist}.alist", known_rank=1, device=-1)       # (the graph arrays only)
+    dv, dc, cn = cd.graph()
+
+    class code:
+        nvar, nchk = cd.nvar, cd.nchk
+    dec = L.BPDecoder(cd.nvar, cd.nchk, dv, dc, cn, device=0)
     dec.set_exit_conditions(it, False, False)
     t0 = time.perf_counter(); llr, _ = awgn_llr(1, 0, 0, min(B, 256), code.nvar, 0.78); t_host = (time.perf_counter() - t0) / min(B, 256)
     llr = np.tile(llr, (B // len(llr) + 1, 1))[:B]
