@@ -17,10 +17,18 @@
  * Decoding (flooding, IT++ convention: LLR > 0 <=> bit 0):
  *   start        : if pisc and every check is satisfied by the signs of the input -> return 0, output = input
  *                  every edge of variable node v carries LLRin[v]
- *   iteration k  : check node of degree 2: the two messages are swapped; degree >= 3: left / right partial boxplus sums
- *                  ml[i] = boxplus(ml[i-1], m[i]), mr[i] = boxplus(mr[i-1], m[n-1-i]); out[0] = mr[n-2], out[n-1] = ml[n-2],
- *                  out[i] = boxplus(ml[i-1], mr[n-2-i])  (IT++ hard-codes other association orders for degrees 3..6; this
- *                  build uses the general form for every degree);
+ *   iteration k  : check node of degree 2: the two messages are swapped;
+ *                  degree 3..6: the association orders IT++ 4.3.1 spells out (boxplus with the table correction is not
+ *                  associative), with mXY = boxplus of inputs X..Y built pairwise:
+ *                    3: out0 = (m1,m2), out1 = (m0,m2), out2 = (m0,m1)
+ *                    4: m01, m23;  out0 = (m1,m23), out1 = (m0,m23), out2 = (m01,m3), out3 = (m01,m2)
+ *                    5: m01, m02 = (m01,m2), m34, m24 = (m2,m34);  out0 = (m1,m24), out1 = (m0,m24), out2 = (m01,m34),
+ *                       out3 = (m02,m4), out4 = (m02,m3)
+ *                    6: m01, m23, m45, m03 = (m01,m23), m25 = (m23,m45), m0145 = (m01,m45);  out0 = (m1,m25), out1 = (m0,m25),
+ *                       out2 = (m0145,m3), out3 = (m0145,m2), out4 = (m03,m5), out5 = (m03,m4)
+ *                  (stated from the published IT++ 4.3.1 source as recalled -- the source is not available here to check);
+ *                  degree >= 7: left / right partial boxplus sums ml[i] = boxplus(ml[i-1], m[i]),
+ *                  mr[i] = boxplus(mr[i-1], m[n-1-i]); out[0] = mr[n-2], out[n-1] = ml[n-2], out[i] = boxplus(ml[i-1], mr[n-2-i]);
  *                  variable node: s = LLRin[v] + sum of incoming; LLRout[v] = clip(s); message to check c = clip(s - incoming from c);
  *                  if psc and every check is satisfied by the signs of LLRout -> return k
  *   end          : return -max_iters  (IT++ reports success only through the syndrome check: without psc every frame returns

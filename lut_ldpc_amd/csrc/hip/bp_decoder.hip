@@ -127,6 +127,29 @@ __global__ __launch_bounds__(256) void bp_cn_kernel(const int32_t *__restrict__ 
             mcv[(size_t)ix[0] * Bp + f] = b; mcv[(size_t)ix[1] * Bp + f] = a;
             continue;
         }
+        if (n <= 6) {
+            // IT++ 4.3.1 spells the check update out for degrees 3..6 with these association orders (include/lut_ldpc_bp.h)
+            int q[6];
+            for (int i = 0; i < 6; i++) q[i] = i < n ? mvc[(size_t)ix[i] * Bp + f] : 0;
+            int o[6];
+            if (n == 3) {
+                o[0] = bp_boxplus(T, P, q[1], q[2]); o[1] = bp_boxplus(T, P, q[0], q[2]); o[2] = bp_boxplus(T, P, q[0], q[1]);
+            } else if (n == 4) {
+                const int m01 = bp_boxplus(T, P, q[0], q[1]), m23 = bp_boxplus(T, P, q[2], q[3]);
+                o[0] = bp_boxplus(T, P, q[1], m23); o[1] = bp_boxplus(T, P, q[0], m23); o[2] = bp_boxplus(T, P, m01, q[3]); o[3] = bp_boxplus(T, P, m01, q[2]);
+            } else if (n == 5) {
+                const int m01 = bp_boxplus(T, P, q[0], q[1]), m02 = bp_boxplus(T, P, m01, q[2]), m34 = bp_boxplus(T, P, q[3], q[4]), m24 = bp_boxplus(T, P, q[2], m34);
+                o[0] = bp_boxplus(T, P, q[1], m24); o[1] = bp_boxplus(T, P, q[0], m24); o[2] = bp_boxplus(T, P, m01, m34);
+                o[3] = bp_boxplus(T, P, m02, q[4]); o[4] = bp_boxplus(T, P, m02, q[3]);
+            } else {
+                const int m01 = bp_boxplus(T, P, q[0], q[1]), m23 = bp_boxplus(T, P, q[2], q[3]), m45 = bp_boxplus(T, P, q[4], q[5]);
+                const int m03 = bp_boxplus(T, P, m01, m23), m25 = bp_boxplus(T, P, m23, m45), m0145 = bp_boxplus(T, P, m01, m45);
+                o[0] = bp_boxplus(T, P, q[1], m25); o[1] = bp_boxplus(T, P, q[0], m25); o[2] = bp_boxplus(T, P, m0145, q[3]);
+                o[3] = bp_boxplus(T, P, m0145, q[2]); o[4] = bp_boxplus(T, P, m03, q[5]); o[5] = bp_boxplus(T, P, m03, q[4]);
+            }
+            for (int i = 0; i < 6; i++) if (i < n) mcv[(size_t)ix[i] * Bp + f] = o[i];
+            continue;
+        }
         // up: mcv[e_i] <- ml[i-1] = boxplus of m[0..i-1] (left-associated), i = 1..n-1
         int acc = mvc[(size_t)ix[0] * Bp + f];
         for (int i = 1; i < n; i++) {

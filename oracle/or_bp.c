@@ -78,6 +78,29 @@ static int decode_one(const or_bp *b, const int *in, int *out, int *mvc, int *mc
             const int n = H->dc[c];
             const int *ix = b->cn_msg_idx + e;
             if (n == 2) { mcv[ix[0]] = mvc[ix[1]]; mcv[ix[1]] = mvc[ix[0]]; }
+            else if (n <= 6) {
+                /* IT++ 4.3.1 spells the check update out for degrees 3..6 with these association orders (boxplus with the table
+                 * correction is not associative, so the order is part of the result) */
+                int q[6];
+                for (int i = 0; i < n; i++) q[i] = mvc[ix[i]];
+                if (n == 3) {
+                    mcv[ix[0]] = boxplus(b, q[1], q[2]); mcv[ix[1]] = boxplus(b, q[0], q[2]); mcv[ix[2]] = boxplus(b, q[0], q[1]);
+                } else if (n == 4) {
+                    const int m01 = boxplus(b, q[0], q[1]), m23 = boxplus(b, q[2], q[3]);
+                    mcv[ix[0]] = boxplus(b, q[1], m23); mcv[ix[1]] = boxplus(b, q[0], m23);
+                    mcv[ix[2]] = boxplus(b, m01, q[3]); mcv[ix[3]] = boxplus(b, m01, q[2]);
+                } else if (n == 5) {
+                    const int m01 = boxplus(b, q[0], q[1]), m02 = boxplus(b, m01, q[2]), m34 = boxplus(b, q[3], q[4]), m24 = boxplus(b, q[2], m34);
+                    mcv[ix[0]] = boxplus(b, q[1], m24); mcv[ix[1]] = boxplus(b, q[0], m24); mcv[ix[2]] = boxplus(b, m01, m34);
+                    mcv[ix[3]] = boxplus(b, m02, q[4]); mcv[ix[4]] = boxplus(b, m02, q[3]);
+                } else {
+                    const int m01 = boxplus(b, q[0], q[1]), m23 = boxplus(b, q[2], q[3]), m45 = boxplus(b, q[4], q[5]);
+                    const int m03 = boxplus(b, m01, m23), m25 = boxplus(b, m23, m45), m0145 = boxplus(b, m01, m45);
+                    mcv[ix[0]] = boxplus(b, q[1], m25); mcv[ix[1]] = boxplus(b, q[0], m25);
+                    mcv[ix[2]] = boxplus(b, m0145, q[3]); mcv[ix[3]] = boxplus(b, m0145, q[2]);
+                    mcv[ix[4]] = boxplus(b, m03, q[5]); mcv[ix[5]] = boxplus(b, m03, q[4]);
+                }
+            }
             else {
                 for (int i = 0; i < n; i++) m[i] = mvc[ix[i]];
                 ml[0] = m[0]; mr[0] = m[n - 1];

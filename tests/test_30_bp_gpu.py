@@ -1,12 +1,12 @@
 """[BP] comparison decoder on the GPU against the oracle's statement of the same specification (include/lut_ldpc_bp.h):
-every decided bit, every output QLLR and every return code, jac-log table and min-sum, all exit modes, check degrees 6 to 32
-(the general left/right partial-sum form), a degree-1 variable node (DVB-S2), ragged batches.  PARITY UNPINNED against the
+every decided bit, every output QLLR and every return code, jac-log table and min-sum, all exit modes, check degrees 3 to 32
+(the spelled-out orders of degrees 3..6 and the general left/right partial-sum form), a degree-1 variable node (DVB-S2), ragged batches.  PARITY UNPINNED against the
 reference's forked IT++ (absent): this pins the two implementations of this repository to each other."""
 import numpy as np
 import pytest
 
 import lut_ldpc_amd as L
-from helpers import CODES
+from helpers import CODES, write_ira_alist
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,23 @@ def test_bp_matches_oracle(alist, rate, snr, B, iters, d):
     q = np.clip(np.floor(0.5 + llr * 2.0 ** d[0]), -(2 ** (d[3] - 1) - 1), 2 ** (d[3] - 1) - 1).astype(np.int32)
     gb2, gi2 = dec.decode_qllr_batch(q)
     assert (gb2 == gb).all() and (gi2 == gi).all()
+    dec.close()
+
+
+@pytest.mark.parametrize("K,dc", [(100, 3), (200, 4), (300, 5), (400, 6), (500, 7)])
+def test_bp_spelled_out_check_degrees(tmp_path, K, dc):
+    """Check degrees 3..6 (association orders written out, include/lut_ldpc_bp.h) and 7 (first general one), jac-log table."""
+    N, M = write_ira_alist(tmp_path / "c.alist", K, 300, 3, seed=dc)
+    code = orc.Code(tmp_path / "c.alist")
+    assert set(code.dc.tolist()) == {dc}
+    ref = orc.BP(code)
+    dec = L.BPDecoder(code.nvar, code.nchk, code.dv, code.dc, code.cn_msg_idx, device=0)
+    llr = _llr(code, 130, 2.0 + 0.5 * (7 - dc), seed=dc, rate=K / N)
+    for psc in (True, False):
+        ref.set_exit_conditions(20, psc, psc); dec.set_exit_conditions(20, psc, psc)
+        wb, wi, wq = ref.decode_llr_batch(llr)
+        gb, gi, gq = dec.decode_llr_batch(llr, want_qllr=True)
+        assert (gi == wi).all() and (gq == wq).all() and (gb == wb).all()
     dec.close()
 
 

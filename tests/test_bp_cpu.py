@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import lut_ldpc_amd as L
-from helpers import CODES
+from helpers import CODES, write_ira_alist
 from oracle import oracle as orc
 
 
@@ -70,3 +70,35 @@ def test_host_awgn_front_end_equals_oracle_and_is_gaussian():
     z = (a * N0 / 4 - 1.0) / np.sqrt(N0 / 2)
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 3).mean()) < 0.05 and abs((z ** 4).mean() - 3) < 0.15
     assert (ua == (a < 0).sum(1)).all()
+
+
+@pytest.mark.parametrize("K,dc", [(100, 3), (200, 4), (300, 5), (400, 6), (500, 7)])
+def test_spelled_out_check_degrees_are_extrinsic(tmp_path, K, dc):
+    """Degrees 3..6 use association orders written out by hand (include/lut_ldpc_bp.h).  With the table switched off (min-sum)
+    boxplus IS associative, so every order must give the plain extrinsic min-sum result: a numpy flooding decoder written
+    from the textbook rule has to agree with the oracle on every output QLLR after a few iterations."""
+    N, M = write_ira_alist(tmp_path / "c.alist", K, 300, 3, seed=dc)
+    code = orc.Code(tmp_path / "c.alist")
+    assert set(code.dc.tolist()) == {dc}
+    bp = orc.BP(code, 12, 0, 7, 28)
+    its = 4
+    bp.set_exit_conditions(its, False, False)
+    llr = _llr(code, 3, 3.0, seed=dc, rate=K / N)
+    _, _, q = bp.decode_llr_batch(llr)
+    qmax = 2 ** 27 - 1
+    qin = np.clip(np.floor(0.5 + llr * 4096), -qmax, qmax).astype(np.int64)
+    vn_of_edge = np.repeat(np.arange(N), code.dv)                       # VN-major edge ids
+    rows = np.split(np.asarray(code.cn_msg_idx), np.cumsum(code.dc)[:-1])
+    for f in range(3):
+        mvc = qin[f][vn_of_edge].copy()
+        for _ in range(its):
+            mcv = np.zeros_like(mvc)
+            for ix in rows:
+                m = mvc[ix]
+                for i in range(len(ix)):
+                    o = np.delete(m, i)
+                    sign = 1 if ((o > 0).sum() - len(o)) % 2 == 0 else -1      # 0 counts as negative
+                    mcv[ix[i]] = sign * np.abs(o).min()
+            s = qin[f] + np.bincount(vn_of_edge, weights=mcv, minlength=N).astype(np.int64)
+            mvc = np.clip(s[vn_of_edge] - mcv, -qmax, qmax)
+        assert (np.clip(s, -qmax, qmax) == q[f]).all()
