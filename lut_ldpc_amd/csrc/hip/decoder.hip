@@ -951,10 +951,8 @@ int launch_late_hard(lutldpc_decoder *d, bool skewed, int g0, int G, const int32
 
 // kernels_compact.hpp: a check point of one half right after its exit test of iteration ii -- the plan kernel decides on the
 // device whether permuting the slots (active frames first) pays; if not, the row kernels return at once
-constexpr unsigned kPermuteBlocks = 1024;
-// LDS of permute_rows_kernel: the row tiles of four waves + the 16-bit descriptors of every label of the half
-size_t permute_lds_bytes(const lutldpc_decoder *d, int GH) { return (size_t)4 * GH * 64 * sizeof(uint32_t) + (size_t)GH * d->tile() * sizeof(uint16_t); }
-bool compaction_fits(const lutldpc_decoder *d, int GH) { return GH <= kPermuteMaxGroups && permute_lds_bytes(d, GH) <= 64 * 1024; }
+constexpr unsigned kPermuteBlocks = 512;      // two 16-wave blocks per CU
+bool compaction_fits(const lutldpc_decoder *, int GH) { return GH <= kPermuteMaxGroups; }
 // A check point costs six short launches per half (~30 us) whether it permutes or not: automatic mode switches compaction on
 // only where one iteration of the batch lasts long enough to make that noise (estimated from its row traffic at 5.5 TB/s);
 // LUTLDPC_COMPACT=1 / 0 forces it on / off.
@@ -977,15 +975,14 @@ int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     if (int rc = launch_late_hard(d, true, h.g0, h.G, ctl)) return rc;
     hipLaunchKernelGGL(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
                        d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, late ? 1 : 0);
-    const size_t lds = permute_lds_bytes(d, h.G);
-    auto rows = [&](uint8_t *buf, int n_rows, int gather) {
-        const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((n_rows + 3) / 4));
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(blocks), dim3(256), lds, d->stream, buf, n_rows, n_rows, h.g0, h.G,
+    // (the grid is fixed and small: an empty check point must cost microseconds)
+    auto rows = [&](uint8_t *a, int na, uint8_t *b, int nb, int gather) {
+        const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((na + nb + kPermuteRows - 1) / kPermuteRows));
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(blocks), dim3(1024), kPermuteLdsBytes, d->stream, a, na, b, nb, h.g0, h.G,
                                             d->d_perm.p, d->d_ctl.p + 4 * hf, gather));
     };
-    rows(d->d_msgs.p, d->E, 1);
-    rows(d->d_cha_t.p, d->nvar, 1);
-    rows(d->d_hard.p, d->nvar, 0);
+    rows(d->d_msgs.p, d->E, d->d_cha_t.p, d->nvar, 1);
+    rows(d->d_hard.p, d->nvar, nullptr, 0, 0);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -995,8 +992,8 @@ int launch_uncompaction(lutldpc_decoder *d, const HalfRange (&half)[2], int Bpad
     hipLaunchKernelGGL(invert_map_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, d->d_slot_of.p, 0, Bpad);
     for (int hf = 0; hf < 2; hf++) {
         if (half[hf].G <= 0) continue;
-        const size_t lds = permute_lds_bytes(d, half[hf].G);
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(std::min<unsigned>(kPermuteBlocks, (unsigned)((d->nvar + 3) / 4))), dim3(256), lds, d->stream, d->d_hard.p, d->nvar, d->nvar,
+        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(std::min<unsigned>(kPermuteBlocks, (unsigned)((d->nvar + kPermuteRows - 1) / kPermuteRows))), dim3(1024),
+                                            kPermuteLdsBytes, d->stream, d->d_hard.p, d->nvar, (uint8_t *)nullptr, 0,
                                             half[hf].g0, half[hf].G, d->d_slot_of.p, (const int32_t *)nullptr, 0));
     }
     hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_iters.p, d->d_slot_of.p, d->d_iters_tmp.p, 0, Bpad);

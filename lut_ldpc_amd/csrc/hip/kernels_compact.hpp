@@ -10,7 +10,7 @@
 // of the ACTIVE frames are moved (finished frames never read theirs again).
 //
 // One permutation = compact_apply_kernel (one block per half: prefix sum, small per-slot arrays) +
-// permute_rows_kernel over the E message rows, the N channel rows and the N decided-bit rows.
+// permute_rows_kernel over the E message rows and the N channel rows (one launch) and over the N decided-bit rows.
 //
 // Whether a permutation pays is decided ON THE DEVICE at every check point (the launch sequence is a fixed hipGraph): it
 // moves  (live + new) groups of message / channel rows  and all decided-bit rows -- measured 1.4 ms for half a 16384-frame
@@ -129,59 +129,110 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t *__restri
     if (i < n) dst[s0 + i] = src[map[s0 + i]];
 }
 
-// rows[g][r][256 B], groups g0 .. g0+GH-1 (one half): row r of every group is rebuilt as
+// rows[g][r][256 B], groups g0 .. g0+GH-1 (one half): row r of every group is rebuilt IN PLACE as
 //     new slot s  <-  old slot perm[s]        (slots relative to the half: perm values are absolute, s0 = g0 * tile)
 // for the first `limit` new slots only (limit = n_active[0] when gather_active, else all).
-// The permutation is the same for every row, so a block first turns it into DESCRIPTORS in LDS -- for every label of
-// every new dword {dword index in the wave's tile of old rows, bit offset}, 16 bits -- and then streams rows: a wave loads
-// the `gold` old dwords of its lane (eight loads in flight), parks them in its LDS tile, and assembles every new dword
-// from F picks {LDS read, shift, mask, merge}.  Memory-bound: (gold + gnew) rows of traffic per row index.
-// LDS: [4 waves][GH][64] dwords + [gnew][64][F] descriptors (GH <= 32: dword index < 2048 = 11 bits, bit offset 5 bits).
-constexpr int kPermuteMaxGroups = 32;
+// The permutation is the same for every row.  A block of 16 waves walks row indices, kPermuteRows at a time: wave w fetches
+// the old rows of groups w and w + 16 (prefetched one step ahead), parks them in the block's LDS tile, and -- after the
+// barrier that also makes the in-place update safe: every old row of the step has been read before any new row is stored --
+// builds the new rows of groups w and w + 16.  The picks of a lane's new dword are the same for every row index and live in
+// registers: for each of its F labels {byte address in the tile, bit offset}, so one label costs ds_read_b32 + v_bfe_u32 +
+// v_lshl_or_b32.  Labels without a source read a row of zeros.  The tile is double-buffered (one barrier per step).
+// Memory-bound: (gold + gnew) rows of traffic per row index, each old row fetched once.  Two row arrays (message rows,
+// channel rows) share one launch: same permutation, same picks.
+// LDS: [2 buffers][kPermuteRows][kPermuteMaxGroups + 1][64] dwords = 64 KB (fixed strides: the offsets are immediates).
+constexpr int kPermuteMaxGroups = 31;
+constexpr int kPermuteRows = 4;
+constexpr int kPermuteRowStride = (kPermuteMaxGroups + 1) * 64;          // dwords per row index in the tile
+constexpr int kPermuteLdsBytes = 2 * kPermuteRows * kPermuteRowStride * 4;
 template <int PACK>
-__global__ __launch_bounds__(256) void permute_rows_kernel(uint8_t *__restrict__ rows, int n_rows, int rows_per_group, int g0, int GH,
-                                                           const int32_t *__restrict__ perm, const int32_t *__restrict__ ctl, int gather_active)
+__global__ __launch_bounds__(1024) void permute_rows_kernel(uint8_t *__restrict__ rows_a, int n_rows_a, uint8_t *__restrict__ rows_b, int n_rows_b, int g0, int GH,
+                                                            const int32_t *__restrict__ perm, const int32_t *__restrict__ ctl, int gather_active)
 {
-    constexpr int F = 4 * PACK, BITS = 8 / PACK, T = kRowBytes * PACK;
-    extern __shared__ uint32_t tile[];                        // [4 waves][GH][64] | descriptors
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int F = 4 * PACK, BITS = 8 / PACK, T = kRowBytes * PACK, R = kPermuteRows;
+    extern __shared__ uint32_t tile[];                        // [2][R][kPermuteMaxGroups + 1][64]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (ctl && ctl[1]) return;                                 // the plan kernel found nothing to gain (block-uniform)
-    uint32_t *my = tile + (size_t)w * GH * 64;
-    uint16_t *desc = reinterpret_cast<uint16_t *>(tile + (size_t)4 * GH * 64);
     const int s0 = g0 * T;
     const int limit = gather_active ? ctl[0] : GH * T;
     const int gnew = (limit + T - 1) / T;                      // groups that receive frames
     const int gold = (ctl && gather_active) ? ctl[3] : GH;     // groups that still held active frames before this permutation
     if (gnew == 0) return;
-    for (int i = threadIdx.x; i < gnew * T; i += 256) {        // new slot i of the half = (group i / T, lane (i % T) / F, label i % F)
-        const int o = perm[s0 + i] - s0;                       // old slot within the half
-        const int go = o / T, fo = o - go * T, lo = fo / F, jo = fo - lo * F;
-        // label jo of a lane sits at half jo / 4, byte jo % 4 (kernels_common.hpp): bit offset 8 * (jo % 4) + BITS * (jo / 4)
-        desc[i] = go < gold ? (uint16_t)((go * 64 + lo) | ((8 * (jo & 3) + BITS * (jo >> 2)) << 11)) : (uint16_t)0xFFFFu;
-    }
-    __syncthreads();
-    // a fixed, small grid walks the rows (an empty check point must cost microseconds, not one block per row)
-    for (int r = blockIdx.x * 4 + w; r < n_rows; r += gridDim.x * 4) {
-        for (int gb = 0; gb < gold; gb += 8) {                 // eight row loads in flight per lane
-            uint32_t v[8];
+
+    // the picks of this lane's dwords of new groups w and w + 16
+    uint32_t addr[2][F], sh[2][F];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                v[k] = gb + k < gold ? *reinterpret_cast<const uint32_t *>(rows + ((size_t)(g0 + gb + k) * rows_per_group + r) * kRowBytes + lane * 4) : 0u;
+    for (int h = 0; h < 2; h++) {
+        const int g = w + 16 * h;
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (gb + k < gold) my[(gb + k) * 64 + lane] = v[k];
-        }
-        // (wave-private tile: no barrier needed, the LDS queue is in order within a wave)
-        for (int g = 0; g < gnew; g++) {
-            uint32_t out = 0;
-            const uint16_t *dd = desc + ((size_t)g * 64 + lane) * F;
-#pragma unroll
-            for (int j = 0; j < F; j++) {
-                const uint32_t de = dd[j];
-                const uint32_t v = de != 0xFFFFu ? (my[de & 0x7FFu] >> (de >> 11)) & ((1u << BITS) - 1u) : 0u;
-                out |= v << (8 * (j & 3) + BITS * (j >> 2));
+        for (int j = 0; j < F; j++) {
+            const int i = g * T + lane * F + j;                // new slot within the half
+            int go = kPermuteMaxGroups, lo = lane, jo = 0;     // no source: the row of zeros
+            if (g < gnew && i < limit) {
+                const int o = perm[s0 + i] - s0;               // old slot within the half
+                const int og = o / T, fo = o - og * T;
+                if (og < gold) { go = og; lo = fo / F; jo = fo - lo * F; }
             }
-            *reinterpret_cast<uint32_t *>(rows + ((size_t)(g0 + g) * rows_per_group + r) * kRowBytes + lane * 4) = out;
+            addr[h][j] = (uint32_t)((go * 64 + lo) * 4);
+            // label jo of a lane sits at half jo / 4, byte jo % 4 (kernels_common.hpp): bit offset 8 * (jo % 4) + BITS * (jo / 4)
+            sh[h][j] = (uint32_t)(8 * (jo & 3) + BITS * (jo >> 2));
         }
+    }
+    for (int i = threadIdx.x; i < 2 * R * 64; i += 1024)       // the rows of zeros
+        tile[(i / 64) * kPermuteRowStride + kPermuteMaxGroups * 64 + (i & 63)] = 0u;
+
+    const int n_rows = n_rows_a + n_rows_b;
+    const bool load0 = w < gold, load1 = w + 16 < gold, own0 = w < gnew, own1 = w + 16 < gnew;      // wave-uniform
+    auto row_ptr = [&](int r, int g) -> uint8_t * {            // row r of the two arrays taken as one, group g (r < n_rows)
+        const bool in_a = r < n_rows_a;
+        return (in_a ? rows_a + ((size_t)(g0 + g) * n_rows_a + r) * kRowBytes : rows_b + ((size_t)(g0 + g) * n_rows_b + (r - n_rows_a)) * kRowBytes) + lane * 4;
+    };
+    uint32_t pv[R][2];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int r = r0 + q;
+            pv[q][0] = (load0 && r < n_rows) ? *reinterpret_cast<const uint32_t *>(row_ptr(r, w)) : 0u;
+            pv[q][1] = (load1 && r < n_rows) ? *reinterpret_cast<const uint32_t *>(row_ptr(r, w + 16)) : 0u;
+        }
+    };
+    auto step = [&](auto BUF, int r0, int r_next) {
+        constexpr int buf = decltype(BUF)::value;
+        uint32_t *tb = tile + buf * R * kPermuteRowStride;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            if (load0) tb[q * kPermuteRowStride + w * 64 + lane] = pv[q][0];
+            if (load1) tb[q * kPermuteRowStride + (w + 16) * 64 + lane] = pv[q][1];
+        }
+        prefetch(r_next);                                      // in flight while this step's rows are assembled
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (!(h ? own1 : own0)) continue;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (r0 + q >= n_rows) continue;
+                const uint8_t *tq = reinterpret_cast<const uint8_t *>(tb + q * kPermuteRowStride);
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < F; j++)
+                    out = lshl_or(__builtin_amdgcn_ubfe(*reinterpret_cast<const uint32_t *>(tq + addr[h][j]), sh[h][j], (uint32_t)BITS),
+                                  (uint32_t)(8 * (j & 3) + BITS * (j >> 2)), out);
+                *reinterpret_cast<uint32_t *>(row_ptr(r0 + q, w + 16 * h)) = out;
+            }
+        }
+    };
+    // a fixed, small grid walks the rows (an empty check point must cost microseconds, not one block per row)
+    const int stride = (int)gridDim.x * R;
+    int r0 = (int)blockIdx.x * R;
+    prefetch(r0);
+    __syncthreads();                                           // the rows of zeros are in place
+    while (r0 < n_rows) {                                      // block-uniform
+        step(std::integral_constant<int, 0>{}, r0, r0 + stride);
+        r0 += stride;
+        if (r0 >= n_rows) break;
+        step(std::integral_constant<int, 1>{}, r0, r0 + stride);
+        r0 += stride;
     }
 }
 

@@ -85,14 +85,14 @@ def awgn_labels(cd, B, snr_db, seed, mode=0):
     return cha, msg, llr
 
 
-def compare(cd, dec, cha, msg, psc, pisc, max_iters=None):
+def compare(cd, dec, cha, msg, psc, pisc, max_iters=None, flat=False):
     """Decode the same labels with the oracle and through the C-ABI: every decided bit and every returned iteration
     code (src/LDPC_Code_LUT.cpp:259-353) must be equal.  Returns the iteration codes."""
     I = max_iters or cd.max_iters
     cd.set_exit_conditions(I, psc, pisc)
     dec.set_exit_conditions(I, psc, pisc)
     # long codes: the oracle's flat-table mode on all cores (bit-identical to its faithful mode: tests/test_oracle_flat.py)
-    want_bits, want_it = (cd.lut_decode_batch_flat if cd.code.nvar >= 10000 else cd.lut_decode_batch)(cha, msg)
+    want_bits, want_it = (cd.lut_decode_batch_flat if (flat or cd.code.nvar >= 10000) else cd.lut_decode_batch)(cha, msg)
     got_bits, got_it = dec.lut_decode_batch(cha, msg)
     assert (want_it == got_it).all(), (np.flatnonzero(want_it != got_it)[:8], want_it[:8], got_it[:8])
     bad = np.argwhere(want_bits != got_bits)

@@ -97,3 +97,23 @@ def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
     _compare(cd, dec, cha, msg, True, False)
     _compare(cd, dec, cha, msg, False, False)
     dec.close()
+
+
+@pytest.mark.parametrize("env,B", [({}, 512 * 36 + 77), ({"LUTLDPC_PACK": "1"}, 256 * 40 + 5)])
+def test_compaction_with_many_groups(env, B, monkeypatch):
+    """Halves of 18-20 frame groups: every wave of the row-permutation kernel fetches and builds two groups (w and w + 16),
+    frames travel across many groups, several permutations per decode.  Oracle: flat-table mode on all cores."""
+    monkeypatch.setenv("LUTLDPC_COMPACT", "1")
+    monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
+    monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "3")
+    monkeypatch.setenv("LUTLDPC_COMPACT_MARGIN", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cd = oracle_codec("n500_q4")
+    dec = product_decoder(cd)
+    assert dec.describe()["compaction"] == 1
+    cha, msg, _ = awgn_labels(cd, B, 2.0, seed=99)
+    it = _compare(cd, dec, cha, msg, True, True, flat=True)
+    assert len(set(it.tolist())) > 8
+    _compare(cd, dec, cha, msg, True, False, flat=True)
+    dec.close()
