@@ -176,9 +176,9 @@ __device__ __forceinline__ void cn_minsum_body(
                             const uint32_t vp = lds_tab[lshl_or(c, CH.tab_shift, b)], vt = lds_tab[lshl_or(c, CH.tab_shift, a)];
                             o_prev = lshl_or(vp, sb, o_prev);
                             o_this = lshl_or(vt, sb, o_this);
-                            if (CH.check) dif = lshl_or(((vp ^ vt) >> CH.sbit_out) & 1u, sb, dif);    // the two outgoing signs differ
                         }
                     }
+                    if (CH.check) dif = ((o_prev ^ o_this) >> CH.sbit_out) & ONE;    // the two outgoing signs differ (all frames of the dword at once)
                     chainfail |= dif;
                     st_row(base, (uint32_t)pend_e * kRowBytes, lane4, bfi(smask, o_prev, pend_old));
                     r[0] = o_this;
@@ -430,7 +430,6 @@ __device__ __forceinline__ void vn_balanced_body(
                     else top = in[0];
                     hardw = lshl_or(lut1(lds_tab, NI, top, ch, shr) < 1u ? 1u : 0u, s, hardw);     // src/LDPC_Code_LUT.cpp:342
                 } else {
-                    uint32_t r0 = 0, diff = 0;
 #pragma unroll
                     for (int o = 0; o < DV; o++) {
                         uint32_t r;
@@ -444,16 +443,19 @@ __device__ __forceinline__ void vn_balanced_body(
                             r = lut1(lds_tab, NI, top, ch, shr);
                         }
                         out[o] = lshl_or(r, s, out[o]);
-                        if (CHECK) { if (o == 0) r0 = r; else diff |= r ^ r0; }
-                    }
-                    if (CHECK) {
-                        // sign of a label = bit sbit (nz = 1 << sbit): negative (bit 1 decided) <=> bit clear;
-                        // the node fails the unanimity test when any two outgoing signs differ
-                        if (P.write_hard) hardw = lshl_or(((r0 >> sbit) & 1u) ^ 1u, s, hardw);      // (wave-uniform; off when the bits are recovered at the end)
-                        failw = lshl_or((diff >> sbit) & 1u, s, failw);
                     }
                 }
             }
+        }
+        if constexpr (KIND == TT_VAR && CHECK) {
+            // sign of a label = bit sbit (nz = 1 << sbit): negative (bit 1 decided) <=> bit clear; the node fails the
+            // unanimity test when any two outgoing signs differ -- on the packed rows, all frames of the dword at once
+            constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;
+            uint32_t diff = 0;
+#pragma unroll
+            for (int o = 1; o < DV; o++) diff |= out[o] ^ out[0];
+            failw |= (diff >> sbit) & ONE;
+            if (P.write_hard) hardw = (~out[0] >> sbit) & ONE;      // (wave-uniform; off when the bits are recovered at the end)
         }
         if constexpr (KIND == TT_DEC) {
             store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
