@@ -214,10 +214,15 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         use_gpu = torch.cuda.is_available()
+        # LUTLDPC_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share cards,
+        # counters travel over gloo); the default on GPUs is RCCL, one card per rank
+        backend = os.environ.get("LUTLDPC_DIST_BACKEND", "nccl" if use_gpu else "gloo")
+        if use_gpu and backend != "nccl":
+            local %= torch.cuda.device_count()
         if use_gpu:
             torch.cuda.set_device(local)
-        dist.init_process_group("nccl" if use_gpu else "gloo")
-        comm = Comm(dist, torch.device("cuda", local) if use_gpu else torch.device("cpu"))
+        dist.init_process_group(backend)
+        comm = Comm(dist, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
     run(params, args.basedir, args.seed, args.custom_name, comm, device=local)
     if world > 1:
         comm.dist.destroy_process_group()

@@ -1,7 +1,9 @@
 """Monte-Carlo driver on the GPU against the oracle's frame-by-frame loop: device sampler, sim_batch,
 the C++ LDPC_BER_Sim_LUT (ber_sim) end to end, results file."""
+import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -163,3 +165,30 @@ def test_config4_sweep_on_one_gpu_at_reduced_nframes(tmp_path):
     be = bits[:, :32400].sum(1)
     want = np.stack([it, be > 0, be, unc], 1).astype(np.int32)
     assert (got == want).all(), np.argwhere(got != want)[:5]
+
+
+def test_config4_two_ranks_sharing_the_gpu_equal_one_rank(tmp_path):
+    """The multi-rank ber_sim command line on the GPU: `torch.distributed.run --nproc-per-node 2 -m lut_ldpc_amd.ber_sim` with
+    both ranks on this box's one card (LUTLDPC_DIST_BACKEND=gloo; RCCL needs one card per rank) writes the same result file
+    as the single-process run -- frames dealt to the ranks, counters exchanged, stop rule applied in global frame order."""
+    import re
+    base = tmp_path / "base"
+    (base / "codes").mkdir(parents=True)
+    shutil.copy(CODES / "rate0.50_irreg_dvbs2_N64800.alist", base / "codes")
+    txt = (ROOT / "data" / "params" / "ber.ini.dvbs2_sweep").read_text()
+    params = tmp_path / "ber.ini.dvbs2_sweep"
+    params.write_text(re.sub(r"Nframes\s*=\s*1e6", "Nframes  = 1500", txt))
+    env = dict(os.environ, PYTHONPATH=str(ROOT), LUTLDPC_DIST_BACKEND="gloo")
+    one = subprocess.run([sys.executable, "-m", "lut_ldpc_amd.ber_sim", "-p", str(params), "-b", str(base), "-s", "3", "-c", "_one"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", "-m", "lut_ldpc_amd.ber_sim", "-p", str(params), "-b", str(base), "-s", "3", "-c", "_two"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    res = sorted((base / "results").rglob("*.it"))
+    assert len(res) == 2, res
+    a, b = itload(res[0]), itload(res[1])
+    for k in ("sim_SNRdB", "sim_Nframes", "sim_Ndatabits", "sim_frame_errors", "sim_data_bit_errors", "sim_uncoded_bit_errors"):
+        assert a[k].tolist() == b[k].tolist(), k
+    assert sum(a["sim_Nframes"].tolist()) > 1500
