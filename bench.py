@@ -396,6 +396,9 @@ def main():
         # skewed two-half pipeline: one decode = 2*I launches of pass_fused_kernel which together carry the
         # I check passes and I-1 variable passes of every frame (first/last launch work on one half only)
         fu_bytes = (I * cn_bytes + (I - 1) * vn_bytes) / (2 * I)
+        # as-shipped mode: bytes of the iterations the frames actually executed, spread over the same 2*I launches
+        # (late launches carry fewer frames; a finished frame that still rides along in its group is NOT counted)
+        fu_bytes *= it_eff / I
         # chain fusion (degree-2 variable nodes updated inside the check pass: dual-diagonal codes) removes one write
         # and one read of two rows per such node and iteration from the launches -- the bytes below stay the canonical
         # algorithmic ones of SURVEY 8(d), `traffic` (PMC) shows what the fused design really moves
