@@ -50,7 +50,8 @@ struct Philox {
 };
 
 // cell index = number of thresholds <= u.  The thresholds ascend (checked on the host), so this is an upper-bound
-// binary search: 7 steps over the LDS copy of the table instead of up to 71 64-bit compares per sample.
+// binary search: 7 steps over the LDS copy of the table instead of up to 71 64-bit compares per sample.  (Used once per
+// bucket in the prologue of the sampler; the samples themselves start from their bucket's first cell, below.)
 __device__ __forceinline__ int cell_of(const uint64_t *thr_lds, int n_thr, uint64_t u) {
     int lo = 0, n = n_thr;                    // invariant: thr[0..lo) <= u, answer in [lo, lo + n]
 #pragma unroll
@@ -61,6 +62,20 @@ __device__ __forceinline__ int cell_of(const uint64_t *thr_lds, int n_thr, uint6
         n = right ? n - half - 1 : half;
     }
     return lo;
+}
+// The same cell index, found from the sample's BUCKET: the top kBucketBits bits of u select one of 1024 equal slices of the
+// unit interval, first_lds[bucket] = number of thresholds <= the slice's lower end, and the few thresholds inside the slice are
+// walked one by one (most slices hold none or one; the dense ones sit in the far tails, hit once in ~500 samples).  The
+// walk is a wave loop: it ends when no lane advances.  Same result as cell_of for every u.
+constexpr int kBucketBits = 10;
+__device__ __forceinline__ int cell_from_bucket(const uint64_t *thr_lds, const uint8_t *first_lds, int n_thr, uint64_t u) {
+    int cell = first_lds[(uint32_t)(u >> (64 - kBucketBits))];
+    for (;;) {
+        const bool adv = cell < n_thr && u >= thr_lds[cell < n_thr ? cell : 0];
+        if (!__any(adv)) break;
+        cell += adv ? 1 : 0;
+    }
+    return cell;
 }
 
 // Writes cha_t / msg0_t rows (row layout) for B frames starting at global frame index frame0 and
@@ -73,9 +88,18 @@ __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint
 {
     constexpr int F = 4 * PACK;                                     // frames per lane
     __shared__ uint64_t thr_lds[kMaxCells];
-    if (threadIdx.x < kMaxCells) thr_lds[threadIdx.x] = C.thr[threadIdx.x < C.n_cells - 1 ? threadIdx.x : 0];
-    __syncthreads();
+    __shared__ uint32_t attr_lds[kMaxCells];                        // per cell: cha | neg << 7 | msg << 8 | cha_m << 16 | msg_m << 24 (labels < 128)
+    __shared__ uint8_t first_lds[1 << kBucketBits];
     const int n_thr = C.n_cells - 1;
+    if (threadIdx.x < kMaxCells) {
+        const int t = threadIdx.x < C.n_cells ? threadIdx.x : 0;
+        thr_lds[threadIdx.x] = C.thr[threadIdx.x < n_thr ? threadIdx.x : 0];
+        attr_lds[threadIdx.x] = (uint32_t)C.cha[t] | ((uint32_t)C.neg[t] << 7) | ((uint32_t)C.msg[t] << 8) | ((uint32_t)C.cha_m[t] << 16) | ((uint32_t)C.msg_m[t] << 24);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (1 << kBucketBits); t += 256)
+        first_lds[t] = (uint8_t)cell_of(thr_lds, n_thr, (uint64_t)t << (64 - kBucketBits));
+    __syncthreads();
     const int lane = threadIdx.x & 63, g = blockIdx.y;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int npairs = (N + 1) / 2;
@@ -100,11 +124,12 @@ __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint
             for (int hh = 0; hh < 2; hh++) {
                 const int v = 2 * p + hh;
                 if (v >= N) continue;
-                const int cell = cell_of(thr_lds, n_thr, u[hh]);
+                const int cell = cell_from_bucket(thr_lds, first_lds, n_thr, u[hh]);
                 const int bit = codewords ? codewords[(size_t)fl * N + v] : 0;
-                const uint32_t a = bit ? C.cha_m[cell] : C.cha[cell], m = bit ? C.msg_m[cell] : C.msg[cell];
-                const int sl = bit ? (C.neg[cell] ^ 1) : C.neg[cell];     // slicer decision
-                unc[j] += (sl != bit);
+                const uint32_t at = attr_lds[cell], sel = bit ? at >> 16 : at;
+                const uint32_t a = sel & 0x7Fu, m = (sel >> 8) & 0xFFu;
+                // slicer decision: neg for bit 0, its mirror for bit 1 -- wrong exactly when the cell lies on the negative side
+                unc[j] += (int)((at >> 7) & 1u);
                 ca[hh][j / 4] |= a << (8 * (j & 3));
                 ms[hh][j / 4] |= m << (8 * (j & 3));
             }
