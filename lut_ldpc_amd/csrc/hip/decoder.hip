@@ -126,6 +126,7 @@ struct lutldpc_decoder {
     // (DVB-S2, 4096 frames, repeated runs): short waves win -- 2 degree-8 nodes / 6 degree-7 checks per wave (longer check runs also keep more chain nodes inside a wave).
     int nodes_per_wave = 0, nodes_per_wave_cn = 0;        // 0 = derive from the degree
     int vn_edges_per_wave = 16, cn_edges_per_wave = 42;
+    bool cn_edges_from_env = false;
     int fused_prio = 0;
     // compaction of the surviving frames (kernels_compact.hpp): as-shipped mode, skewed pipeline
     // (off by default: measured on MI355X it does not pay -- DVB-S2 frames finish too late (41.7 of 50 iterations on
@@ -289,7 +290,9 @@ void build_fast_index(lutldpc_decoder *d) {
     std::vector<int> back((size_t)d->nchk, 0), fwd((size_t)d->nchk, 0);
     std::vector<char> internal((size_t)d->nvar, 0);
     // checks per wave: a class of wide checks whose members are mostly linked by degree-2 nodes (the zigzag of a dual-diagonal
-    // code) gets at least four checks per wave, so that three of four links fall inside a wave
+    // code) gets at least four checks per wave, so that three of four links fall inside a wave -- and twelve where the class is
+    // large enough to keep 2048 runs per frame group (DVB-S2: 11 of 12 links inside a wave, +0.9 % over six checks per wave;
+    // 18 per wave is slower again, tools/env_sweep.sh)
     d->cn_npw_class.assign(d->cclass.size(), 0);
     if (d->use_chain && d->min_lut) {
         std::vector<int> cand(d->cclass.size(), 0);
@@ -300,7 +303,11 @@ void build_fast_index(lutldpc_decoder *d) {
             if (std::abs(pos_of[(size_t)c1] - pos_of[(size_t)c2]) == 1) cand[(size_t)cls_of[(size_t)c1]]++;
         }
         for (size_t ci = 0; ci < d->cclass.size(); ci++)
-            if (2 * cand[ci] >= (int)d->cclass[ci].nodes.size() && d->nodes_per_wave_cn <= 0) d->cn_npw_class[ci] = std::max(4, d->npw_cn(d->cclass[ci].deg));
+            if (2 * cand[ci] >= (int)d->cclass[ci].nodes.size() && d->nodes_per_wave_cn <= 0) {
+                const int n = (int)d->cclass[ci].nodes.size();
+                d->cn_npw_class[ci] = std::max(4, d->npw_cn(d->cclass[ci].deg));
+                if (!d->cn_edges_from_env) d->cn_npw_class[ci] = std::max(d->cn_npw_class[ci], std::min(12, n / 2048));
+            }
     }
     if (d->use_chain && d->min_lut)
         for (int v = 0; v < d->nvar; v++) {
@@ -1323,7 +1330,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave = v; }
     d->nodes_per_wave_cn = d->nodes_per_wave;
     if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
-    if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->cn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) { d->cn_edges_per_wave = v; d->cn_edges_from_env = true; } }
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;

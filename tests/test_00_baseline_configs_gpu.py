@@ -40,7 +40,7 @@ def test_c3_c2_full_iteration_count_default_path(name, snr, n_oracle):
     desc = dec.describe()
     assert desc["pack"] == 2 and desc["skewed_pipeline"] == 1 and desc["use_fast"] == 1, desc
     if name == "dvbs2_q4":
-        assert desc["fused_bucket"] == 0 and desc["chain_nodes"] == 26999, desc
+        assert desc["fused_bucket"] == 0 and desc["chain_nodes"] == 29699, desc
     B = 1100
     cha, msg, _ = awgn_labels(cd, B, snr, seed=2026)
     for psc in (True, False):

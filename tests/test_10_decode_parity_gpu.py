@@ -88,10 +88,11 @@ def test_generated_kernels_are_used_and_match(name, monkeypatch):
 
 
 def test_chain_fusion_is_on_for_the_dual_diagonal_code():
-    """DVB-S2: 5 of 6 parity nodes (degree 2, checks c and c+1) are updated inside the check pass in fixed-work mode."""
+    """DVB-S2: 11 of 12 parity nodes (degree 2, checks c and c+1; twelve checks per wave) are updated inside the check pass in
+    fixed-work mode."""
     cd = oracle_codec("dvbs2_q4_i6")
     dec = product_decoder(cd)
-    assert dec.describe()["chain_nodes"] == 26999, dec.describe()
+    assert dec.describe()["chain_nodes"] == 29699, dec.describe()
     cha, msg, _ = awgn_labels(cd, 1030, 1.0, seed=99)          # three frame groups: halves of two and one
     _compare(cd, dec, cha, msg, False, False)
     dec.set_exit_conditions(cd.max_iters, True, False)         # early termination: chain fusion off, same buffers ...
