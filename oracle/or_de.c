@@ -280,6 +280,7 @@ static void collect_level(or_node *n, int req, int cur, or_node **out, int *cnt)
 /* LDPC_DE.cpp:1345-1377 */
 static void joint_root_design(or_tree **trees, int L, const double *degree_dist)
 {
+    if (L <= 0) return;
     for (int dd = 0; dd < L; dd++) { or_dvec p = or_tree_update(trees[dd], 0); or_dvec_free(&p); }
     or_node ***nodes = (or_node ***)malloc(sizeof(or_node **) * (size_t)L);
     int *J = (int *)malloc(sizeof(int) * (size_t)L);
