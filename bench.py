@@ -17,7 +17,8 @@ groups together with the variable pass of the other half (2 x iterations launche
 algorithmic bytes per launch / mean launch duration from HIP events recorded on the decoder's own
 stream while the same K steps are issued once more as plain launches right after the timed region
 (events cannot be recorded inside a graph replay).  `frame_loop` adds the device channel sampler and
-the error counting around the decode (the whole loop of LDPC_BER_Sim::sim_snr_point).
+the error counting around the decode (the whole loop of LDPC_BER_Sim::sim_snr_point); `as_shipped` is the
+same decoder with the reference's default exit test on (parity_check_iter = true), a few extra steps.
 `cpu_baseline` times the oracle (oracle/, the CPU restatement of the reference decoder) on a bounded
 sample of the same workload on this host -- the oracle is used only there.
 """
@@ -228,6 +229,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7, help="extra single steps, each timed on its own, for the median / spread of a step (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not bracket the kernels with HIP events")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--as-shipped-steps", type=int, default=3, help="extra untimed-for-`value` steps with the exit test on (0 = skip; fixed mode only)")
     ap.add_argument("--frame-loop-steps", type=int, default=2, help="extra untimed-for-`value` steps of the full sampler+decode+count loop (0 = skip)")
     args = ap.parse_args()
 
@@ -461,6 +463,31 @@ def main():
                                 "frontend_ms_per_step": pf["frontend"]["ms"] / args.frame_loop_steps,
                                 "frame_errors_last_step": int((st[:, 1] != 0).sum()),
                                 "note": "device sampler (Philox4x32-10 cell sampler) + decode + BER/FER counting, zero codeword"}
+    if args.as_shipped_steps > 0 and not psc:
+        # The reference's default mode (parity_check_iter = true: exit test every iteration, src/LDPC_BER_Sim.cpp:71,500) on
+        # frames 0.4 dB above the design point, where they converge: reported beside `value`, never instead of it.
+        snr_s = snr + 0.4
+        cha_s, msg_s = make_labels_device(cd, B, snr_s, seed=4321 + rank, qcha_map=qcha_map)
+        cd.set_exit_conditions(max_iter, True, True)
+        it_s = torch.empty(B, dtype=torch.int32, device="cuda")
+        bits_s = torch.empty_like(out_bits)                    # (out_bits / out_iters still hold the fixed-work result the oracle checks)
+
+        def step_s(sync):
+            dec.lut_decode_batch_device(cha_s.data_ptr(), msg_s.data_ptr(), B, bits_s.data_ptr(), it_s.data_ptr(), sync=sync)
+        step_s(True); step_s(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.as_shipped_steps):
+            step_s(k == args.as_shipped_steps - 1)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter() - t1
+        result["as_shipped"] = {"codewords_per_s_per_gpu": B * args.as_shipped_steps / t_s, "steps": args.as_shipped_steps,
+                                "EbN0_dB": float(snr_s), "mean_iterations_executed": float(it_s.abs().float().mean().item()),
+                                "frames_that_left_through_the_exit_test": int((it_s > 0).sum().item()),
+                                "note": "parity_check_iter = true (exit test every iteration, finished frames retired by compaction), "
+                                        "same decoder, labels resident in HBM"}
+        cd.set_exit_conditions(max_iter, psc, psc)
+        del cha_s, msg_s, bits_s
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ob, oi, fb, fi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
         n, nf = len(oi), len(fi)
