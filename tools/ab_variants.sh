@@ -11,7 +11,7 @@ for r in $(seq 1 "$rounds"); do
     # a variant is  <build>[:ENV=VAL[,ENV=VAL...]]  -- <build> = default or a directory of lut_ldpc_amd/lib_variants/
     b=${v%%:*}; envs=""; if [ "$b" != "$v" ]; then envs=$(echo "${v#*:}" | tr ',' ' '); fi
     if [ "$b" = default ]; then lib=$root/lut_ldpc_amd/lib/liblut_ldpc_amd.so; else lib=$root/lut_ldpc_amd/lib_variants/$b/liblut_ldpc_amd.so; fi
-    env $envs LUTLDPC_LIB=$lib python "$root/bench.py" --no-cpu-baseline --frame-loop-steps 0 --steps 5 ${BENCH_ARGS} 2>/dev/null | python -c "
+    env $envs LUTLDPC_LIB=$lib python "$root/bench.py" --no-cpu-baseline --frame-loop-steps 0 --as-shipped-steps 0 --steps 5 ${BENCH_ARGS} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 ss=d.get('single_steps') or {}

@@ -11,7 +11,7 @@ grep -o -E "\b(SQC_ICACHE_[A-Z_]+|SQ_IFETCH[A-Z_]*|SQC_INST_[A-Z_]+|SQ_INST_LEVE
 CTR=$(grep -E "^SQC_ICACHE_(REQ|HITS|MISSES|MISSES_DUPLICATE)$" "$R/$OUT/counters_sqc.txt" | tr '\n' ' ')
 echo "counters: $CTR" > "$R/$OUT/summary.txt"
 for i in $(seq 1 "$N"); do
-    rocprofv3 --pmc $CTR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$R/$OUT/run$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --frame-loop-steps 0 --reps 0 > "$R/$OUT/run$i.json" 2> "$R/$OUT/run$i.err"
+    rocprofv3 --pmc $CTR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$R/$OUT/run$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --frame-loop-steps 0 --as-shipped-steps 0 --reps 0 > "$R/$OUT/run$i.json" 2> "$R/$OUT/run$i.err"
     python3 - "$R/$OUT/run$i" >> "$R/$OUT/summary.txt" <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]

@@ -6,7 +6,7 @@ out=$root/gpurun_out/shipped_ab.txt; : > "$out"
 run() {   # label, env..., -- bench args
     local label=$1; shift
     local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-    env "${envs[@]}" python "$root/bench.py" --no-cpu-baseline --frame-loop-steps 0 --reps 0 --steps 5 "$@" 2>/dev/null | python -c "
+    env "${envs[@]}" python "$root/bench.py" --no-cpu-baseline --frame-loop-steps 0 --as-shipped-steps 0 --reps 0 --steps 5 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$label', '%.1f k cw/s' % (d['value']/1e3), 'iters %.1f' % d['config']['mean_iterations_executed'], 'ms/step %.2f' % d['ms_per_step'])" >> "$out"
