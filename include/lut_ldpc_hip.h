@@ -80,6 +80,10 @@ int lutldpc_decoder_set_exit_conditions(lutldpc_decoder *d, int max_iters, int p
  *   out_bits[B*nvar]  decoded bits 0/1           (LLRout)
  *   out_iters[B]      the reference's return value per frame: 0, ii+1, +max_iters or -max_iters
  * Frames are independent; results are bit-identical to calling lut_decode frame by frame.
+ * Errors instead of the reference's it_assert aborts: B <= 0 or a null pointer -> LUTLDPC_ERR_ARG; a handle without a device
+ * -> LUTLDPC_ERR_STATE.  A label outside its alphabet (>= Nq_Cha, >= Nq_Msg[0]) is undefined behaviour in the reference (it
+ * indexes the tables unchecked); here it is clamped to the largest label when the rows are built, so it can never reach
+ * another frame's lane.
  */
 int lutldpc_decoder_decode_batch(lutldpc_decoder *d, const uint8_t *cha, const uint8_t *msg0, int B,
                                  uint8_t *out_bits, int32_t *out_iters);

@@ -175,3 +175,30 @@ def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket):
         assert (it > 0).sum() > 0
         _compare(cd, dec, cha, msg, False, False)
     dec.close()
+
+
+def test_argument_errors_and_out_of_range_labels():
+    """Error codes where the reference aborts (it_assert): an empty batch and a device-less handle are refused.  Labels outside
+    the alphabet (undefined in the reference: unchecked table index) are clamped to the largest label when the rows are
+    built -- the neighbours in the same 256-byte row decode exactly as without the bad frame."""
+    import lut_ldpc_amd as L
+    cd = oracle_codec("n500_q4")
+    dec = product_decoder(cd)
+    cha, msg, _ = awgn_labels(cd, 700, 2.0, seed=31)
+    with pytest.raises(L.LutLdpcError):
+        dec.lut_decode_batch(cha[:0], msg[:0])
+    host_only = product_decoder(cd, device=-1)
+    with pytest.raises(L.LutLdpcError):
+        host_only.lut_decode_batch(cha[:4], msg[:4])
+    host_only.close()
+    dec.set_exit_conditions(cd.max_iters, True, True)
+    good_bits, good_it = dec.lut_decode_batch(cha, msg)
+    bad_c, bad_m = cha.copy(), msg.copy()
+    bad_c[5, ::3] = 200                                       # frame 5: labels far outside the 16-label alphabets
+    bad_m[5, 1::3] = 255
+    bits, it = dec.lut_decode_batch(bad_c, bad_m)
+    keep = np.arange(700) != 5
+    assert (bits[keep] == good_bits[keep]).all() and (it[keep] == good_it[keep]).all()
+    clamp_bits, clamp_it = dec.lut_decode_batch(np.minimum(bad_c, cd.nq_cha - 1), np.minimum(bad_m, cd.nq_msg[0] - 1))
+    assert (bits[5] == clamp_bits[5]).all() and it[5] == clamp_it[5]
+    dec.close()
