@@ -136,3 +136,41 @@ def write_ira_alist(path, K, M, dv_info, seed=0):
         for r in row_cols:
             f.write(" ".join(str(v + 1) for v in sorted(r)) + "\n")
     return N, M
+
+
+def write_random_alist(path, N, M, dv_choices, dv_probs, seed=0):
+    """A random irregular code for the fuzz tests: variable degrees drawn from dv_choices with dv_probs, edges dealt to the M
+    checks as evenly as possible (check degrees differ by at most one), double edges repaired by swapping sockets.
+    Returns (dv, dc) as arrays."""
+    rng = np.random.default_rng(seed)
+    dv = rng.choice(dv_choices, size=N, p=dv_probs).astype(int)
+    E = int(dv.sum())
+    sockets = np.arange(E) % M                                  # check of every socket: degrees E // M or E // M + 1
+    rng.shuffle(sockets)
+    ptr = np.concatenate([[0], np.cumsum(dv)])
+    cols = [list(sockets[ptr[v]:ptr[v + 1]]) for v in range(N)]
+    for _ in range(200):
+        bad = [v for v in range(N) if len(set(cols[v])) < len(cols[v])]
+        if not bad:
+            break
+        for v in bad:
+            for k in range(1, len(cols[v])):
+                if cols[v][k] in cols[v][:k]:
+                    w = int(rng.integers(N)); j = int(rng.integers(len(cols[w])))
+                    if cols[w][j] not in cols[v] and cols[v][k] not in cols[w]:
+                        cols[v][k], cols[w][j] = cols[w][j], cols[v][k]
+    assert all(len(set(c)) == len(c) for c in cols)
+    col_rows = [sorted(int(r) for r in c) for c in cols]
+    row_cols = [[] for _ in range(M)]
+    for v, rows in enumerate(col_rows):
+        for r in rows:
+            row_cols[r].append(v)
+    assert min(len(r) for r in row_cols) >= 2
+    with open(path, "w") as f:
+        f.write(f"{N} {M}\n{max(len(c) for c in col_rows)} {max(len(r) for r in row_cols)}\n")
+        f.write(" ".join(str(len(c)) for c in col_rows) + "\n" + " ".join(str(len(r)) for r in row_cols) + "\n")
+        for c in col_rows:
+            f.write(" ".join(str(r + 1) for r in c) + "\n")
+        for r in row_cols:
+            f.write(" ".join(str(v + 1) for v in sorted(r)) + "\n")
+    return dv, np.array([len(r) for r in row_cols])

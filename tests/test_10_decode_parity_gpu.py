@@ -202,3 +202,38 @@ def test_argument_errors_and_out_of_range_labels():
     clamp_bits, clamp_it = dec.lut_decode_batch(np.minimum(bad_c, cd.nq_cha - 1), np.minimum(bad_m, cd.nq_msg[0] - 1))
     assert (bits[5] == clamp_bits[5]).all() and it[5] == clamp_it[5]
     dec.close()
+
+
+FUZZ = [  # N, M, variable degrees, their shares, Nq_Cha, Nq_Msg, iterations, design sigma, B
+    (600, 300, [2, 3, 6], [0.4, 0.45, 0.15], 16, 16, 9, 0.80, 777),
+    (900, 300, [3, 4], [0.7, 0.3], 16, 16, 7, 0.62, 513),
+    (1200, 600, [2, 3, 9], [0.35, 0.5, 0.15], 16, 8, 8, 0.82, 300),
+    (800, 400, [3], [1.0], 8, 8, 6, 0.80, 1025),
+    (500, 250, [2, 4, 12], [0.45, 0.45, 0.10], 16, 16, 10, 0.85, 64),
+    (1000, 200, [3, 5], [0.8, 0.2], 16, 16, 5, 0.45, 1300),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUZZ)))
+def test_random_irregular_codes(tmp_path, case):
+    """Random irregular graphs the build has never seen (several variable and check degree classes, check degrees that differ
+    by one, wide and narrow checks, 3- and 4-bit alphabets): design with the oracle, decode through the default path, every
+    bit and iteration code against the oracle in all three exit modes, ragged batch sizes."""
+    from helpers import write_random_alist
+    from oracle import oracle as orc
+    N, M, dvc, dvp, nqc, nqm, I, sig, B = FUZZ[case]
+    dv, dc = write_random_alist(tmp_path / "r.alist", N, M, dvc, dvp, seed=100 + case)
+    code = orc.Code(tmp_path / "r.alist")
+    assert len(set(dc.tolist())) >= 1 and code.nvar == N
+    cd = orc.Codec(code, skip_rank=True)
+    cd.set_rank(M)
+    cd.rate = 1.0 - M / N
+    cd.design_luts(sigma2=sig ** 2, max_iters=I, nq_msg=np.full(I, nqm, np.int32), nq_cha=nqc)
+    dec = product_decoder(cd)
+    snr = -10 * np.log10(2 * cd.rate * sig * sig) + 0.5
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=case)
+    it = _compare(cd, dec, cha, msg, True, True)
+    _compare(cd, dec, cha, msg, True, False)
+    _compare(cd, dec, cha, msg, False, False)
+    assert len(set(it.tolist())) >= 2
+    dec.close()
