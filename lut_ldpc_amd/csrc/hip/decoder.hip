@@ -98,6 +98,8 @@ struct lutldpc_decoder {
     // per node, check classes the DEG edge ids per node (no pointer chasing, scalar loads)
     std::vector<int32_t> fast_idx;
     std::vector<int> vn_idx_off, cn_idx_off;                      // per class
+    std::vector<int> cn_nidx_off;                                 // per check class: the NODE of every entry of the edge table (iteration 0 reads the initial-message rows)
+    int first_from_nodes = 1;                                     // LUTLDPC_FIRST_FROM_NODES=0: copy the initial messages to the edge rows first (init_edges_kernel)
     // chain fusion (build_fast_index): per check class the offset of its {back, forward} node table (-1 = no links),
     // per variable class the dense table / count of the nodes NOT updated inside the check pass
     std::vector<int> chain_idx_off, vn_red_off, vn_red_n;
@@ -347,6 +349,18 @@ void build_fast_index(lutldpc_decoder *d) {
             for (int cn : c.nodes) { d->fast_idx.push_back(back[(size_t)cn]); d->fast_idx.push_back(fwd[(size_t)cn]); }
         }
     }
+    // the node behind every entry of the check classes' edge tables, same order
+    {
+        std::vector<int> edge_node((size_t)d->E, 0);
+        for (int v = 0; v < d->nvar; v++)
+            for (int e = d->vn_ptr[(size_t)v]; e < d->vn_ptr[(size_t)v + 1]; e++) edge_node[(size_t)e] = v;
+        d->cn_nidx_off.assign(d->cclass.size(), 0);
+        for (size_t ci = 0; ci < d->cclass.size(); ci++) {
+            const size_t off = (size_t)d->cn_idx_off[ci], cnt = d->cclass[ci].nodes.size() * (size_t)d->cclass[ci].deg;
+            d->cn_nidx_off[ci] = (int)d->fast_idx.size();
+            for (size_t j = 0; j < cnt; j++) d->fast_idx.push_back(edge_node[(size_t)d->fast_idx[off + j]]);
+        }
+    }
     // variable passes that follow a chained check pass skip the nodes it already updated
     for (size_t vi = 0; vi < d->vclass.size(); vi++) {
         if (d->vclass[vi].deg != 2) continue;
@@ -388,6 +402,11 @@ int validate_fast_index(const lutldpc_decoder *d) {
         const size_t off = (size_t)d->cn_idx_off[i], cnt = c.nodes.size() * (size_t)c.deg;
         if (off + cnt > n) return bad("check class table outside the blob");
         for (size_t j = 0; j < cnt; j++) if (d->fast_idx[off + j] < 0 || d->fast_idx[off + j] >= d->E) return bad("check edge out of range");
+        if (i < d->cn_nidx_off.size()) {
+            const size_t no = (size_t)d->cn_nidx_off[i];
+            if (no + cnt > n) return bad("check class node table outside the blob");
+            for (size_t j = 0; j < cnt; j++) if (d->fast_idx[no + j] < 0 || d->fast_idx[no + j] >= d->nvar) return bad("check node out of range");
+        }
         if (d->chain_idx_off[i] >= 0) {
             const size_t co = (size_t)d->chain_idx_off[i];
             if (co + 2 * c.nodes.size() > n) return bad("chain link table outside the blob");
@@ -813,6 +832,7 @@ void add_cn_roles(const lutldpc_decoder *d, FusedParams &FP, std::vector<int> &b
         R.n_nodes = (int)d->cclass[i].nodes.size(); R.nodes_per_wave = npw;
         R.waves_per_group = (R.n_nodes + npw - 1) / npw;
         R.idx_off = d->cn_idx_off[i]; R.E = d->E; R.N = d->nvar; R.nz = nz; R.check = check; R.vfail_stride_w = d->Bcap / 4;
+        if (ii == 0 && d->first_from_nodes) { R.first = 1; R.nidx_off = d->cn_nidx_off[i]; }
         FP.role[FP.n_roles++] = R;
         blocks.push_back((R.waves_per_group * h.G + 3) / 4);
     }
@@ -886,6 +906,7 @@ int validate_fused(const lutldpc_decoder *d, const FusedParams &FP, const std::v
             if (R.deg < 2 || R.deg > kFusedCnDeg[d->fused_bucket_id]) return bad(r, "check degree outside the bucket");
             if (R.idx_off < 0 || (size_t)R.idx_off + (size_t)R.n_nodes * (size_t)R.deg > idx_n) return bad(r, "edge table");
             if (!is_pow2(R.nz) || R.nz > 64) return bad(r, "nz");
+            if (R.first && (R.nidx_off < 0 || (size_t)R.nidx_off + (size_t)R.n_nodes * (size_t)R.deg > idx_n || R.check || R.chain.hard)) return bad(r, "node table of the first check pass");
             if (R.chain.on || R.chain.hard) {
                 if (R.chain.idx_off < 0 || (size_t)R.chain.idx_off + 2 * (size_t)R.n_nodes > idx_n) return bad(r, "chain link table");
                 if (R.chain.on && (R.chain.tab_off < 0 || R.chain.tab_len < 4 || R.chain.tab_len > 1024 || (size_t)R.chain.tab_off + (size_t)R.chain.tab_len > tab_n)) return bad(r, "chain table");
@@ -920,7 +941,7 @@ int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan,
     if (sl.nb == 0) return LUTLDPC_OK;
     Timed t(d, LUTLDPC_K_FUSED_PASS);
 #define FUSED_ARGS d->stream, plan.d_roles.p + sl.role_off, sl.items, sl.nb, d->fused_prio, vn_check, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p, \
-                   reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p
+                   reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p, d->d_msg0_t.p
     if (d->fused_bucket_id == 0) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 0>(FUSED_ARGS)));
     else if (d->fused_bucket_id == 1) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 1>(FUSED_ARGS)));
     else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
@@ -1103,12 +1124,12 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         if ((rc = launch_syndrome(d, G))) return rc;
         if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
     }
-    {   // :284-289
+    const bool skewed = d->skew && d->skew_ok;      // (a single frame group runs the same launches with an empty second half)
+    if (!(skewed && d->first_from_nodes)) {   // :284-289 (the fused pipeline's first check pass reads the initial-message rows itself)
         Timed t(d, LUTLDPC_K_LAYOUT);
         hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
         LAUNCH_CHECK();
     }
-    const bool skewed = d->skew && d->skew_ok;      // (a single frame group runs the same launches with an empty second half)
     if (skewed && (rc = iterate_skewed(d, B, Bpad, G))) return rc;
     for (int ii = 0; ii < I && !skewed; ii++) {   // :301-338
         const int set = d->iter_set[(size_t)ii];
@@ -1330,6 +1351,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_NODES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 4096) d->nodes_per_wave = v; }
     d->nodes_per_wave_cn = d->nodes_per_wave;
     if (const char *e = getenv("LUTLDPC_VN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) d->vn_edges_per_wave = v; }
+    if (const char *e = getenv("LUTLDPC_FIRST_FROM_NODES")) d->first_from_nodes = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) { d->cn_edges_per_wave = v; d->cn_edges_from_env = true; } }
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;

@@ -40,11 +40,14 @@ namespace lutldpc {
 // incoming messages are this check's output r[0] and the previous check's output r[1], held back in `pend` -- and
 // the NEW variable-to-check messages are stored instead of the check-to-variable ones: one write and one read less per
 // such edge and iteration (decoder.hip: build_fast_index puts the chain edges at slots 0 / 1 of the edge table).
-template <int DEG, int UNR, int PACK, bool CHAIN, typename PT>
+// FIRST (the check pass of iteration 0 in the fused pipeline): every edge still carries its variable node's initial message
+// (src/LDPC_Code_LUT.cpp:284-289), so the inputs are read from the N initial-message rows through a second table holding the
+// NODE of every check edge -- the E edge rows are written for the first time by this pass, no separate copy kernel.
+template <int DEG, int UNR, int PACK, bool CHAIN, typename PT, bool FIRST = false>
 __device__ __forceinline__ void cn_minsum_body(
     const PT &P, int block, uint8_t *msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx, const ChainParams CH = ChainParams{}, uint8_t *lds_tab = nullptr,
-    const uint8_t *cha = nullptr, const uint8_t *__restrict__ tables = nullptr, uint8_t *hard = nullptr)
+    const uint8_t *cha = nullptr, const uint8_t *__restrict__ tables = nullptr, uint8_t *hard = nullptr, const uint8_t *msg0 = nullptr)
 {
     static_assert(!CHAIN || (UNR == 1 && DEG >= 2), "chain fusion: one check per step");
     if constexpr (CHAIN) {      // the degree-2 root table (block-uniform call)
@@ -65,6 +68,12 @@ __device__ __forceinline__ void cn_minsum_body(
     const rsrc_t base = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's edge rows
     const uint32_t lane4 = (uint32_t)lane * 4u;
     const int32_t *edges = fast_idx + P.idx_off;
+    const int32_t *nodes = edges;
+    rsrc_t nbase = base;
+    if constexpr (FIRST) {
+        nodes = fast_idx + P.nidx_off;
+        nbase = make_rsrc(msg0 + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes);       // this group's initial-message rows
+    }
     const int first = chunk * P.nodes_per_wave;
     int last = first + P.nodes_per_wave;
     if (last > P.n_nodes) last = P.n_nodes;
@@ -103,7 +112,12 @@ __device__ __forceinline__ void cn_minsum_body(
         for (int u = 0; u < UNR; u++) {
             const uint32_t off = lane4 | ((i + u < last) ? 0u : 0x80000000u);
 #pragma unroll
-            for (int k = 0; k < DEG; k++) xx[u][k] = ld_row(base, (uint32_t)ee[u][k] * kRowBytes, off);
+            for (int k = 0; k < DEG; k++) {
+                if constexpr (FIRST) {
+                    const int ii = (i + u < last) ? i + u : last - 1;
+                    xx[u][k] = ld_row(nbase, (uint32_t)nodes[(size_t)ii * DEG + k] * kRowBytes, off);
+                } else xx[u][k] = ld_row(base, (uint32_t)ee[u][k] * kRowBytes, off);
+            }
             if constexpr (CHAIN) xcn = ld_row(cbase, (uint32_t)(lbn > 0 ? lbn - 1 : 0) * kRowBytes, (i + u < last && lbn > 0 && CH.on) ? lane4 : (lane4 | 0x80000000u));
         }
     };
@@ -535,6 +549,7 @@ struct RoleParams {
     int32_t n_nodes, nodes_per_wave, waves_per_group, idx_off;
     int32_t E, N, nz, shift_msg, check, write_hard;
     int32_t vfail_stride_w, vfail_off_w;
+    int32_t first, nidx_off;   // check roles of iteration 0: inputs from the initial-message rows, through the node table at nidx_off
     ChainParams chain;     // check roles only
     int32_t tab_off[kFusedMaxTables], tab_len[kFusedMaxTables], tab_shift[kFusedMaxTables];
 };
@@ -546,10 +561,11 @@ struct FusedParams {
     RoleParams role[kFusedMaxRoles];
 };
 
-template <int PACK, bool CHAIN, int... Ds>
+template <int PACK, bool CHAIN, bool FIRST, int... Ds>
 __device__ __forceinline__ void fused_cn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *msgs, const uint32_t *state_w,
-                                                uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables, uint8_t *hard) {
-    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables, hard), 0) : 0), ...);
+                                                uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables, uint8_t *hard,
+                                                const uint8_t *msg0) {
+    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN, RoleParams, FIRST>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables, hard, msg0), 0) : 0), ...);
 }
 template <int PACK, bool CHECK, int... Ds>
 __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *lds_tab, uint8_t *msgs,
@@ -564,7 +580,8 @@ __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, 
 template <int PACK, bool CHECK, int BUCKET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? LUTLDPC_B0_WAVES_MIN : BUCKET == 1 ? 4 : 3, BUCKET == 0 ? LUTLDPC_B0_WAVES_MAX : 8))) void pass_fused_kernel(
     const RoleParams *__restrict__ roles, const int2 *__restrict__ items, int prio, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
-    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)
+    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx,
+    const uint8_t *__restrict__ msg0)
 {
     constexpr int MAXVN = kFusedVnDeg[BUCKET], MAXCN = kFusedCnDeg[BUCKET];
     __shared__ __attribute__((aligned(16))) uint8_t lds_tab[MAXVN * kFastTableStride];
@@ -576,8 +593,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0
     }
     if (P.kind == 0) {
         // chain fusion (dual-diagonal codes: DVB-S2 at every rate, IRA): every bucket has the chained check bodies
-        if (P.chain.on || P.chain.hard) fused_cn_switch<PACK, true>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
-        else fused_cn_switch<PACK, false>(P, rb, std::make_integer_sequence<int, MAXCN - 1>{}, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard);
+        constexpr auto degs = std::make_integer_sequence<int, MAXCN - 1>{};
+        if (!P.first) {
+            if (P.chain.on || P.chain.hard) fused_cn_switch<PACK, true, false>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            else fused_cn_switch<PACK, false, false>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+        } else {                           // iteration 0 (two launches per decode): inputs from the initial-message rows
+            if (P.chain.on) fused_cn_switch<PACK, true, true>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            else fused_cn_switch<PACK, false, true>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+        }
     }
     else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
@@ -742,13 +765,13 @@ hipError_t preload_cn_fast() {
 // skewed pipeline: one launch of pass_fused_kernel over n_blocks items
 template <int PACK, int BUCKET>
 void launch_fused(hipStream_t s, const RoleParams *d_roles, const int32_t *items, int n_blocks, int prio, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
-                  const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
+                  const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, const uint8_t *msg0) {
     if (vn_check)
         hipLaunchKernelGGL((pass_fused_kernel<PACK, true, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx);
+                           state_w, vfail_w, tables, fast_idx, msg0);
     else
         hipLaunchKernelGGL((pass_fused_kernel<PACK, false, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx);
+                           state_w, vfail_w, tables, fast_idx, msg0);
 }
 // force the code object of this translation unit onto the current device now (HIP loads code objects lazily, at the first
 // launch of one of their kernels): decoder.hip calls these at decoder creation, see preload_code_objects
@@ -758,7 +781,7 @@ hipError_t preload_fused() {
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&pass_fused_kernel<PACK, false, BUCKET>));
 }
 
-#define LUTLDPC_FUSED_SIG (hipStream_t, const RoleParams *, const int32_t *, int, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *)
+#define LUTLDPC_FUSED_SIG (hipStream_t, const RoleParams *, const int32_t *, int, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, const uint8_t *)
 #define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
     X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
     X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \

@@ -63,11 +63,12 @@ def test_kernel_variants(name, B, snr, env, monkeypatch):
 
 
 @pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2)])
-@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_VALIDATE": "1"}, {"LUTLDPC_LATE_HARD": "0"}])
+@pytest.mark.parametrize("env", [{"LUTLDPC_PACK": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_VALIDATE": "1"}, {"LUTLDPC_LATE_HARD": "0"}, {"LUTLDPC_FIRST_FROM_NODES": "0"}])
 def test_skewed_pipeline_variants(name, B, snr, env, monkeypatch):
     """Byte rows, per-class launches instead of the fused pipeline, the validating debug mode (every role checked against
     the allocation sizes, one stream synchronisation per fused launch), and decided bits stored by every variable pass
-    instead of recovered at the end (LUTLDPC_LATE_HARD=0)."""
+    instead of recovered at the end (LUTLDPC_LATE_HARD=0), the initial messages copied to the edge rows by their own kernel
+    instead of read by the first check pass (LUTLDPC_FIRST_FROM_NODES=0)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cd = oracle_codec(name)
