@@ -136,6 +136,7 @@ struct lutldpc_decoder {
     int use_compact = -1, compact_first = 8, compact_every = 0;     // use: -1 = automatic (long iterations only), every: 0 = automatic
     float compact_margin = 1.0f;                                    // LUTLDPC_COMPACT_MARGIN (0: permute whenever a group falls idle)
     float compact_min_share = 0.35f;                                // ... and at least this share of the live groups falls idle at once
+    int compact_keep = 1;                                           // LUTLDPC_COMPACT_KEEP: the frames that left keep their rows, bits recovered once at the end
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
@@ -996,21 +997,25 @@ int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     if (n <= 0) return LUTLDPC_OK;
     uint8_t *pending = d->d_vfail.p + (size_t)((ii + 1) & 1) * kVfailSlots * d->Bcap;      // flags already raised for the next test
     int32_t *ctl = d->d_ctl.p + 4 * hf;
-    hipLaunchKernelGGL(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
-                       d->compact_margin > 0 ? d->compact_min_share : 0.0f);
     const bool late = late_hard_active(d, true, nullptr);
-    // the decided bits of the frames that left since the last permutation, before their messages are dropped
-    if (int rc = launch_late_hard(d, true, h.g0, h.G, ctl)) return rc;
+    // keep: the frames that left keep their frozen rows (moved behind the active ones), their decided bits are recovered once
+    // at the end of the decode like without compaction; otherwise (LUTLDPC_COMPACT_KEEP=0) they are recovered at the check point
+    // and the rows dropped
+    const bool keep = late && d->compact_keep;
+    hipLaunchKernelGGL(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
+                       d->compact_margin > 0 ? d->compact_min_share : 0.0f, keep ? 1 : 0);
+    // (not keep) the decided bits of the frames that left since the last permutation, before their messages are dropped
+    if (!keep) if (int rc = launch_late_hard(d, true, h.g0, h.G, ctl)) return rc;
     hipLaunchKernelGGL(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
-                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, late ? 1 : 0);
+                       d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, (late && !keep) ? 1 : 0);
     // (the grid is fixed and small: an empty check point must cost microseconds)
     auto rows = [&](uint8_t *a, int na, uint8_t *b, int nb, int gather) {
         const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((na + nb + kPermuteRows - 1) / kPermuteRows));
         PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(blocks), dim3(1024), kPermuteLdsBytes, d->stream, a, na, b, nb, h.g0, h.G,
                                             d->d_perm.p, d->d_ctl.p + 4 * hf, gather));
     };
-    rows(d->d_msgs.p, d->E, d->d_cha_t.p, d->nvar, 1);
-    rows(d->d_hard.p, d->nvar, nullptr, 0, 0);
+    rows(d->d_msgs.p, d->E, d->d_cha_t.p, d->nvar, keep ? 2 : 1);
+    if (!keep) rows(d->d_hard.p, d->nvar, nullptr, 0, 0);        // (keep: no decided bit exists before the end of the decode)
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -1149,6 +1154,13 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     {   // decided bits of the frames that left through the exit test, from their frozen messages (see late_hard_active)
         Timed t(d, LUTLDPC_K_LAYOUT);
         if ((rc = launch_late_hard(d, skewed, 0, G, nullptr))) return rc;
+        if (skewed && d->psc && d->pisc && compaction_on(d, G) && late_hard_active(d, true, nullptr) && d->compact_keep) {
+            // frames that passed the test on the channel decisions may have been moved by a permutation: their decided-bit rows
+            // did not travel (no decided bit exists during the iterations), their channel rows did
+            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
+                                                d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), N, d->Nq_Cha / 2, 0));
+            LAUNCH_CHECK();
+        }
     }
     // :340-349
     if ((rc = launch_tree_pass<TT_DEC>(d, d->dec_plan[(size_t)last_set], &d->dec_fast[(size_t)last_set], d->dec_jit.empty() ? nullptr : &d->dec_jit[(size_t)last_set], G, 0, 0, 0, LUTLDPC_K_DECISION))) return rc;
@@ -1356,6 +1368,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_COMPACT_KEEP")) d->compact_keep = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT_EVERY")) { int v = atoi(e); if (v >= 1) d->compact_every = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT_MARGIN")) { double v = atof(e); if (v >= 0 && v < 100) d->compact_margin = (float)v; }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void compact_init_kernel(int32_t *__restrict__
 // `min_share` of the live groups fall idle AND the group-iterations saved reach `margin` x the rows moved (header of this
 // file; margin 0 = whenever a group falls idle, for the tests).
 __global__ __launch_bounds__(1024) void compact_decide_kernel(const uint8_t *__restrict__ state, int s0, int n, int tile_frames, int32_t *__restrict__ ctl,
-                                                               int iters_left, float margin, float min_share)
+                                                               int iters_left, float margin, float min_share, int rows_keep)
 {
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void compact_decide_kernel(const uint8_t *__r
         for (int k = 0; k < 16; k++) s += wsum[k];
         const int gnew = (s + tile_frames - 1) / tile_frames, live = ctl[2], gh = n / tile_frames;
         const float gain = (float)(live - gnew) * (float)iters_left;
-        const float cost = 0.7f * (float)(live + gnew) + 0.3f * (float)gh;
+        const float cost = rows_keep ? 1.3f * (float)live : 0.7f * (float)(live + gnew) + 0.3f * (float)gh;
         ctl[0] = s;
         if (gnew < live && (float)(live - gnew) >= min_share * (float)live && gain >= margin * cost) { ctl[1] = 0; ctl[3] = live; ctl[2] = gnew; }
         else ctl[1] = 1;
@@ -154,9 +154,13 @@ __global__ __launch_bounds__(1024) void permute_rows_kernel(uint8_t *__restrict_
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (ctl && ctl[1]) return;                                 // the plan kernel found nothing to gain (block-uniform)
     const int s0 = g0 * T;
-    const int limit = gather_active ? ctl[0] : GH * T;
-    const int gnew = (limit + T - 1) / T;                      // groups that receive frames
+    // gather_active 1: only the active frames move (the first ctl[0] new slots; the rest of their rows is dropped)
+    //               2: every frame of the groups that were live before this permutation moves -- the frames that just left keep
+    //                  their (frozen) rows, now behind the active ones; frames that left earlier sit further back and stay put
+    //               0: every slot of the half
     const int gold = (ctl && gather_active) ? ctl[3] : GH;     // groups that still held active frames before this permutation
+    const int limit = gather_active == 1 ? ctl[0] : gather_active == 2 ? gold * T : GH * T;
+    const int gnew = (limit + T - 1) / T;                      // groups that receive frames
     if (gnew == 0) return;
 
     // the picks of this lane's dwords of new groups w and w + 16

@@ -401,6 +401,28 @@ __global__ __launch_bounds__(256) void hard_from_labels_kernel(const uint8_t *__
     reinterpret_cast<uint32_t *>(hard)[i] = pack_halves<PACK>(r);
 }
 
+// hard[g][v][:] = cha[g][v][:] < nz for the frames that passed the test on the channel decisions (ST_DONE_PISC) only: used at
+// the end of a decode whose compaction moved frames (the channel rows travel with their frame, the decided-bit rows do not)
+template <int PACK>
+__global__ __launch_bounds__(256) void hard_from_labels_masked_kernel(const uint8_t *__restrict__ cha_t, uint8_t *__restrict__ hard,
+                                                                      const uint32_t *__restrict__ state_w, int N, int nz, int g0)
+{
+    const int lane = threadIdx.x & 63, g = g0 + blockIdx.y;
+    uint32_t m[PACK], any = 0;
+#pragma unroll
+    for (int h = 0; h < PACK; h++) { m[h] = swar_zero_mask(state_w[frame_word<PACK>(g, lane, h)] ^ (ST_DONE_PISC * 0x01010101u)); any |= m[h]; }
+    if (wave_all_zero(any)) return;
+    const uint32_t smask = pack_masks<PACK>(m);
+    const int w0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), step = (int)gridDim.x * 4;
+    for (int v = w0; v < N; v += step) {
+        const uint32_t x = *reinterpret_cast<const uint32_t *>(cha_t + ((size_t)g * N + (size_t)v) * kRowBytes + lane * 4);
+        uint32_t r[PACK];
+#pragma unroll
+        for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), (uint32_t)nz);
+        store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hard + ((size_t)g * N + (size_t)v) * kRowBytes + lane * 4), pack_halves<PACK>(r), smask);
+    }
+}
+
 // Decided bits of the frames that left through the exit test (ST_DONE_PSC), recovered ONCE at the end of the decode from
 // their frozen messages instead of being stored by every variable pass.  The reference returns the unanimous signs of the
 // variable-to-check messages of iteration ii (src/LDPC_Code_LUT.cpp:327-329,437-452); here the frame is frozen one check

@@ -114,7 +114,27 @@ def test_compaction_with_many_groups(env, B, monkeypatch):
     dec = product_decoder(cd)
     assert dec.describe()["compaction"] == 1
     cha, msg, _ = awgn_labels(cd, B, 2.0, seed=99)
+    for f in (3, 600, 5000, B - 2):                            # noise-free frames: they pass the test on the channel decisions (pisc) and
+        cha[f] = cd.nq_cha - 1                                 # are moved by the first permutation like every other finished frame
+        msg[f] = cd.nq_msg[0] - 1
     it = _compare(cd, dec, cha, msg, True, True, flat=True)
-    assert len(set(it.tolist())) > 8
+    assert len(set(it.tolist())) > 8 and (it == 0).sum() == 4
     _compare(cd, dec, cha, msg, True, False, flat=True)
+    dec.close()
+
+
+def test_compaction_that_drops_the_rows_of_finished_frames(monkeypatch):
+    """LUTLDPC_COMPACT_KEEP=0: the earlier flow -- decided bits recovered at every permuting check point, only the active frames'
+    rows moved, decided-bit rows permuted along."""
+    monkeypatch.setenv("LUTLDPC_COMPACT", "1")
+    monkeypatch.setenv("LUTLDPC_COMPACT_KEEP", "0")
+    monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
+    monkeypatch.setenv("LUTLDPC_COMPACT_EVERY", "2")
+    monkeypatch.setenv("LUTLDPC_COMPACT_MARGIN", "0")
+    cd = oracle_codec("n500_q4")
+    dec = product_decoder(cd)
+    cha, msg, _ = awgn_labels(cd, 512 * 9 + 40, 2.0, seed=7)
+    cha[11] = cd.nq_cha - 1; msg[11] = cd.nq_msg[0] - 1
+    it = _compare(cd, dec, cha, msg, True, True, flat=True)
+    assert len(set(it.tolist())) > 8 and (it == 0).sum() == 1
     dec.close()
