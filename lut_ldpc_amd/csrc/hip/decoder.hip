@@ -138,6 +138,7 @@ struct lutldpc_decoder {
     float compact_min_share = 0.35f;                                // ... and at least this share of the live groups falls idle at once
     int compact_keep = 1;                                           // LUTLDPC_COMPACT_KEEP: the frames that left keep their rows, bits recovered once at the end
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
+    DevBuf<int32_t> d_grp;                           // per frame group: every frame failed the probe of the test on the channel decisions
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
     // them and they are never unloaded)
@@ -600,6 +601,7 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(d->d_iters.alloc((size_t)Bpad));
     HIP_TRY(d->d_frame_of.alloc((size_t)Bpad)); HIP_TRY(d->d_perm.alloc((size_t)Bpad)); HIP_TRY(d->d_tmp3.alloc((size_t)Bpad * 3));
     HIP_TRY(d->d_ctl.alloc(8)); HIP_TRY(d->d_slot_of.alloc((size_t)Bpad)); HIP_TRY(d->d_iters_tmp.alloc((size_t)Bpad));
+    HIP_TRY(d->d_grp.alloc(G));
     d->Bcap = Bpad;
     return LUTLDPC_OK;
 }
@@ -636,7 +638,23 @@ int launch_syndrome(lutldpc_decoder *d, int G, int sel = 0) {
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
     PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                        reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p + (size_t)sel * kVfailSlots * d->Bcap),
-                       d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw, d->Bcap / 4));
+                       d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw, d->Bcap / 4, -1, (const int32_t *)nullptr, (int32_t *)nullptr));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+// The test on the channel decisions (src/LDPC_Code_LUT.cpp:275-279) straight off the channel-label rows: a one-wave probe over
+// the first 64 checks of every group, then the full pass, which skips the groups whose frames have all failed in the probe.
+// The decided bits of the frames that pass are written at the end of the decode (hard_from_labels_masked_kernel).
+int launch_syndrome_of_labels(lutldpc_decoder *d, int G) {
+    Timed t(d, LUTLDPC_K_SYNDROME);
+    const int cpw = 8, sbit = __builtin_ctz((unsigned)(d->Nq_Cha / 2));
+    HIP_TRY(hipMemsetAsync(d->d_grp.p, 0, sizeof(int32_t) * (size_t)G, d->stream));
+#define SYN_ARGS(CPW, SKIP, OUT) d->d_cha_t.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_ptr.p, \
+                     reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, CPW, d->Bcap / 4, sbit, SKIP, OUT
+    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(1u, (unsigned)G), dim3(64), 0, d->stream, SYN_ARGS(64, (const int32_t *)nullptr, d->d_grp.p)));
+    unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
+    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, SYN_ARGS(cpw, (const int32_t *)d->d_grp.p, (int32_t *)nullptr)));
+#undef SYN_ARGS
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -1120,14 +1138,14 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
     if (d->pisc) {   // :275-279
-        {
+        if ((rc = launch_syndrome_of_labels(d, G))) return rc;
+        if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
+        {   // decided bits of the frames that passed = signs of their channel labels (:275); groups without such a frame return at once
             Timed t(d, LUTLDPC_K_LAYOUT);
-            size_t nw = (size_t)G * N * kRowBytes / 4;
-            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_kernel<PK>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, nw, d->Nq_Cha / 2));
+            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
+                                                d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), N, d->Nq_Cha / 2, 0));
             LAUNCH_CHECK();
         }
-        if ((rc = launch_syndrome(d, G))) return rc;
-        if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
     }
     const bool skewed = d->skew && d->skew_ok;      // (a single frame group runs the same launches with an empty second half)
     if (!(skewed && d->first_from_nodes)) {   // :284-289 (the fused pipeline's first check pass reads the initial-message rows itself)
@@ -1156,7 +1174,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         if ((rc = launch_late_hard(d, skewed, 0, G, nullptr))) return rc;
         if (skewed && d->psc && d->pisc && compaction_on(d, G) && late_hard_active(d, true, nullptr) && d->compact_keep) {
             // frames that passed the test on the channel decisions may have been moved by a permutation: their decided-bit rows
-            // did not travel (no decided bit exists during the iterations), their channel rows did
+            // did not travel (no other decided bit exists during the iterations), their channel rows did -- write the bits again
             PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
                                                 d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), N, d->Nq_Cha / 2, 0));
             LAUNCH_CHECK();
@@ -1408,7 +1426,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->d_ops.release(); d->d_tables.release(); d->d_msgs.release(); d->d_cha_t.release(); d->d_msg0_t.release(); d->d_hard.release();
         d->d_state.release(); d->d_vfail.release(); d->d_iters.release(); d->d_in_cha.release(); d->d_in_msg.release(); d->d_out_bits.release();
         d->drop_graphs();
-        d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release();
+        d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release(); d->d_grp.release();
         d->drop_plans();
         d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);

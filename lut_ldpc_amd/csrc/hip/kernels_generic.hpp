@@ -507,12 +507,19 @@ __global__ __launch_bounds__(256) void chain_hard_kernel(uint8_t *__restrict__ h
 // the eight indices (lanes 0..7), v_readlane turns them into wave-uniform row offsets, the eight row
 // loads go out together (a lane offset past the end of the run is out of range: returns 0, neutral
 // for the XOR), and the running parity is closed branch-free where the flag is set.
+// label_sbit >= 0: the rows are LABEL rows (channel labels), the decided bit of a label is its sign bit inverted (label < nz,
+// nz = 1 << label_sbit: src/LDPC_Code_LUT.cpp:275) -- the test on the channel decisions needs no decided-bit rows.
+// grp_skip (optional): groups whose frames have ALL failed already are skipped; grp_out (optional, one wave per group: the probe
+// launch over the first checks): set to 1 when every active frame of the group has failed.  At an SNR where the channel
+// decisions never form a codeword the probe fails every frame within its 64 checks and the full launch returns at once.
 template <int PACK>
 __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__restrict__ hard, const uint32_t *__restrict__ state_w,
                                                             uint32_t *__restrict__ vfail_w, const int32_t *__restrict__ cn_ptr,
-                                                            const uint32_t *__restrict__ cn_vnf, int M, int N, int checks_per_wave, int vfail_stride_w)
+                                                            const uint32_t *__restrict__ cn_vnf, int M, int N, int checks_per_wave, int vfail_stride_w,
+                                                            int label_sbit = -1, const int32_t *__restrict__ grp_skip = nullptr, int32_t *__restrict__ grp_out = nullptr)
 {
     const int lane = threadIdx.x & 63, g = blockIdx.y;
+    if (grp_skip && grp_skip[g]) return;
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__res
             const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
             last[j] = (k + j < k1) ? (uint32_t)((int32_t)e >> 31) : 0u;                      // 0 or ~0, wave-uniform
             x[j] = ld_row(hb, (e & 0x7FFFFFFFu) * kRowBytes, lane4 | (k + j < k1 ? 0u : 0x80000000u));
+            if (label_sbit >= 0) x[j] = (k + j < k1) ? ((~x[j] >> label_sbit) & (PACK == 2 ? 0x11111111u : 0x01010101u)) : 0u;     // (wave-uniform)
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -543,6 +551,12 @@ __global__ __launch_bounds__(256) void syndrome_bits_kernel(const uint8_t *__res
 #pragma unroll
     for (int h = 0; h < PACK; h++) fail[h] = unpack_half<PACK>(acc, h);
     flag_frames<PACK>(vfail_w, vfail_stride_w, g, lane, fail, amask);
+    if (grp_out) {
+        bool all_failed = true;
+#pragma unroll
+        for (int h = 0; h < PACK; h++) all_failed = all_failed && (((fail[h] | ~amask[h]) & 0x01010101u) == 0x01010101u);
+        if (__ballot(!all_failed) == 0ull && lane == 0) grp_out[g] = 1;
+    }
 }
 
 // per-frame state machine between passes
