@@ -512,6 +512,9 @@ int preload_code_objects(int device) {
     HIP_TRY((preload_fused<2, 0>())); HIP_TRY((preload_fused<2, 1>())); HIP_TRY((preload_fused<2, 2>()));
     HIP_TRY((preload_vn_fast<TT_VAR, 1>())); HIP_TRY((preload_vn_fast<TT_VAR, 2>())); HIP_TRY((preload_vn_fast<TT_DEC, 2>()));
     HIP_TRY((preload_cn_fast<2>()));
+    // the row permutation of the compaction uses 66 KB of dynamic LDS (kernels_compact.hpp)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&permute_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPermuteLdsBytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&permute_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kPermuteLdsBytes));
     HIP_TRY(hipDeviceSynchronize());
     done.push_back(device);
     return LUTLDPC_OK;

@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t *__restri
 // v_lshl_or_b32.  Labels without a source read a row of zeros.  The tile is double-buffered (one barrier per step).
 // Memory-bound: (gold + gnew) rows of traffic per row index, each old row fetched once.  Two row arrays (message rows,
 // channel rows) share one launch: same permutation, same picks.
-// LDS: [2 buffers][kPermuteRows][kPermuteMaxGroups + 1][64] dwords = 64 KB (fixed strides: the offsets are immediates).
-constexpr int kPermuteMaxGroups = 31;
+// LDS: [2 buffers][kPermuteRows][kPermuteMaxGroups + 1][64] dwords = 66 KB (fixed strides: the offsets are immediates; two blocks
+// per CU; above the 64 KB a launch gets by default: decoder.hip raises hipFuncAttributeMaxDynamicSharedMemorySize once).
+constexpr int kPermuteMaxGroups = 32;
 constexpr int kPermuteRows = 4;
 constexpr int kPermuteRowStride = (kPermuteMaxGroups + 1) * 64;          // dwords per row index in the tile
 constexpr int kPermuteLdsBytes = 2 * kPermuteRows * kPermuteRowStride * 4;

@@ -146,10 +146,11 @@ LDPC_BER_Sim::LDPC_BER_Sim(const std::string &params, const std::string &base) :
     save_permuted = ini.get("LDPC.save_permuted", false);
     parity_check_iter = ini.get("LDPC.parity_check_iter", true);
     max_iter = ini.get("BP.max_iter", 30);
-    // build-side: upper bound of the frames per device call.  16384 is the measured optimum on MI355X for the N = 64800 codes
-    // (+7 % over 4096: launch tails weigh less; 3.4 GB of rows) and costs the short codes nothing; the frame loop still
+    // build-side: upper bound of the frames per device call.  32768 is the measured optimum on MI355X for the N = 64800 codes
+    // (+7 % over 4096: launch tails weigh less; +3 % over 16384 with early termination: two halves of 32 frame groups, the most
+    // the compaction of the surviving frames takes; 6.8 GB of rows) and costs the short codes nothing; the frame loop still
     // starts at 256 frames and quadruples (sim_snr_point), so a point that stops after Nfers errors wastes little work
-    batch_frames = ini.get("Sim.batch_frames", 16384);
+    batch_frames = ini.get("Sim.batch_frames", 32768);
     codes_path = join(base, codes_dir);
     results_path = join(base, results_dir);
     fs::create_directories(codes_path);

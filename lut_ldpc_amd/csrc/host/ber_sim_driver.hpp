@@ -89,7 +89,7 @@ public:
     LDPC_BER_Sim_Results results;
     // build-side knobs
     int device = 0;
-    int batch_frames = 16384;        // frames per device call (upper bound; INI key Sim.batch_frames)
+    int batch_frames = 32768;        // frames per device call (upper bound; INI key Sim.batch_frames)
     bool quiet = false;
 
 protected:

@@ -156,6 +156,13 @@ hipError_t hipFuncGetAttributes(void *attr, const void *func)
     for (int i = 0; i < g_nfuncs; i++) if (g_funcs[i].host == func) return hipSuccess;
     return fail("hipFuncGetAttributes: function was never registered");
 }
+hipError_t hipFuncSetAttribute(const void *func, int attr, int value)
+{
+    (void)attr;
+    if (value < 0 || value > 160 * 1024) return fail("hipFuncSetAttribute: dynamic LDS beyond 160 KB");
+    for (int i = 0; i < g_nfuncs; i++) if (g_funcs[i].host == func) return hipSuccess;
+    return fail("hipFuncSetAttribute: function was never registered");
+}
 hipError_t hipDeviceSynchronize(void) { if (g_capturing) return fail("hipDeviceSynchronize during capture"); return hipSuccess; }
 hipError_t hipModuleLoadData(void **mod, const void *image) { if (!image) return fail("hipModuleLoadData(NULL)"); *mod = malloc(8); return hipSuccess; }
 hipError_t hipModuleUnload(void *mod) { free(mod); return hipSuccess; }

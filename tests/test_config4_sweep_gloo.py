@@ -32,7 +32,7 @@ def test_two_gloo_ranks_equal_one_process_on_the_config4_sweep(tmp_path):
     # the committed file with Nframes reduced (12 frames per point) and small device batches, everything else untouched
     txt = (ROOT / "data" / "params" / "ber.ini.dvbs2_sweep").read_text()
     txt = re.sub(r"Nframes\s*=\s*1e6", "Nframes  = 12", txt)
-    txt = re.sub(r"batch_frames\s*=\s*16384", "batch_frames = 4", txt)
+    txt = re.sub(r"batch_frames\s*=\s*32768", "batch_frames = 4", txt)
     params.write_text(txt)
     worker = str(ROOT / "tests" / "_gloo_worker_c4.py")
     one, two = tmp_path / "one.json", tmp_path / "two.json"

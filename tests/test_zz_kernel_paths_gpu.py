@@ -100,9 +100,10 @@ def test_compaction_of_surviving_frames(name, B, snr, monkeypatch):
     dec.close()
 
 
-@pytest.mark.parametrize("env,B", [({}, 512 * 36 + 77), ({"LUTLDPC_PACK": "1"}, 256 * 40 + 5)])
+@pytest.mark.parametrize("env,B", [({}, 512 * 36 + 77), ({"LUTLDPC_PACK": "1"}, 256 * 40 + 5), ({}, 512 * 64 - 3)])
 def test_compaction_with_many_groups(env, B, monkeypatch):
-    """Halves of 18-20 frame groups: every wave of the row-permutation kernel fetches and builds two groups (w and w + 16),
+    """Halves of 18-20 frame groups (and of 32, the most the row kernel takes: 66 KB of LDS, two groups for every wave): every
+    wave of the row-permutation kernel fetches and builds two groups (w and w + 16),
     frames travel across many groups, several permutations per decode.  Oracle: flat-table mode on all cores."""
     monkeypatch.setenv("LUTLDPC_COMPACT", "1")
     monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "3")
