@@ -1003,7 +1003,7 @@ int launch_late_hard(lutldpc_decoder *d, bool skewed, int g0, int G, const int32
 // device whether permuting the slots (active frames first) pays; if not, the row kernels return at once
 constexpr unsigned kPermuteBlocks = 512;      // two 16-wave blocks per CU
 bool compaction_fits(const lutldpc_decoder *, int GH) { return GH <= kPermuteMaxGroups; }
-// A check point costs six short launches per half (~30 us) whether it permutes or not: automatic mode switches compaction on
+// A check point costs three short launches per half (~15 us) whether it permutes or not: automatic mode switches compaction on
 // only where one iteration of the batch lasts long enough to make that noise (estimated from its row traffic at 5.5 TB/s);
 // LUTLDPC_COMPACT=1 / 0 forces it on / off.
 bool compaction_on(const lutldpc_decoder *d, int G) {
@@ -1109,7 +1109,7 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
         pp = std::move(np);
     }
     const lutldpc_decoder::SkewPlan &plan = *pp;
-    // compaction of the surviving frames: check points every `every` iterations (a check point costs four short launches
+    // compaction of the surviving frames: check points every `every` iterations (a check point costs three short launches
     // per half: keep that below a few per cent of an iteration, whose duration is estimated from its row traffic)
     const bool compact = psc && compaction_on(d, G);
     const int every = d->compact_every > 0 ? d->compact_every : 2;

@@ -4,23 +4,26 @@
 // 512-frame group is done, which rarely happens while a few stragglers need 40+ iterations.  Every few
 // iterations the frame SLOTS of a half are therefore permuted -- active frames to the front (stable), all
 // others behind them -- so that whole groups fall idle and their waves exit on the first look at the state
-// words (load_active).  Nothing is lost: the decided bits, iteration codes, states and pending flags move
-// with their frame, `frame_of[slot]` remembers where each frame came from, and at the end of the decode the
-// decided bits and iteration codes are put back into the original order.  Only the message and channel rows
-// of the ACTIVE frames are moved (finished frames never read theirs again).
+// words (load_active).  Nothing is lost: iteration codes, states and pending flags move with their frame,
+// `frame_of[slot]` remembers where each frame came from, and at the end of the decode the decided bits and
+// iteration codes are put back into the original order.
 //
+// Default flow (rows kept): the message and channel rows of EVERY frame of the groups that were live move -- the
+// frames that just left keep their frozen rows behind the active ones (frames that left earlier sit further back; a
+// stable partition never touches them) -- so the decided bits are recovered once at the end of the decode, exactly
+// as without compaction, and no decided-bit row exists (or moves) before that.
 // One permutation = compact_apply_kernel (one block per half: prefix sum, small per-slot arrays) +
-// permute_rows_kernel over the E message rows and the N channel rows (one launch) and over the N decided-bit rows.
+// permute_rows_kernel over the E message rows and the N channel rows (one launch).
+// Earlier flow (LUTLDPC_COMPACT_KEEP=0, also used when the decided bits are stored by every variable pass): the
+// decided bits of the frames that left since the last permutation are recovered at the check point
+// (hard_from_frozen_kernel, frames marked ST_DONE_SAVED), only the ACTIVE frames' rows move, and the N decided-bit
+// rows are permuted along.
 //
 // Whether a permutation pays is decided ON THE DEVICE at every check point (the launch sequence is a fixed hipGraph): it
-// moves  (live + new) groups of message / channel rows  and all decided-bit rows -- measured 1.4 ms for half a 16384-frame
-// DVB-S2 batch, about  0.7 (live + new) + 0.3 GH  group-iterations -- and saves  (live - new) groups x remaining
-// iterations.  compact_decide_kernel permutes only when a sizeable share of the live groups falls idle at once and the
-// saving exceeds the cost; otherwise the other kernels of the check point return at once (5 us each).
-//
-// A check point = compact_decide_kernel -> hard_from_frozen_kernel (the decided bits of the frames that left since the
-// last permutation are read off their frozen messages BEFORE those are dropped, kernels_generic.hpp) ->
-// compact_apply_kernel -> permute_rows_kernel x 3.
+// reads and rewrites the rows of the live groups -- about  1.3 x live  group-iterations (earlier flow:
+// 0.7 (live + new) + 0.3 GH) -- and saves  (live - new) groups x remaining iterations.  compact_decide_kernel permutes
+// only when a sizeable share of the live groups falls idle at once and the saving exceeds the cost; otherwise the
+// other kernels of the check point return at once (5 us each).
 #pragma once
 #include "kernels_common.hpp"
 
