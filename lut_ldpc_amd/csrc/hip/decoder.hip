@@ -321,7 +321,7 @@ void build_fast_index(lutldpc_decoder *d) {
             if (c1 < 0 || c2 < 0 || c1 == c2 || cls_of[(size_t)c1] != cls_of[(size_t)c2]) continue;
             if (pos_of[(size_t)c1] > pos_of[(size_t)c2]) std::swap(c1, c2);
             const int deg = d->cclass[(size_t)cls_of[(size_t)c1]].deg, npw = d->npw_cn_class((size_t)cls_of[(size_t)c1]);
-            if (deg < 2 || deg > kFusedCnDeg[kFusedBuckets - 1] || pos_of[(size_t)c2] != pos_of[(size_t)c1] + 1 || pos_of[(size_t)c1] / npw != pos_of[(size_t)c2] / npw) continue;
+            if (deg < 2 || deg > fused_max_cn_deg() || pos_of[(size_t)c2] != pos_of[(size_t)c1] + 1 || pos_of[(size_t)c1] / npw != pos_of[(size_t)c2] / npw) continue;
             if (fwd[(size_t)c1] || back[(size_t)c2]) continue;
             fwd[(size_t)c1] = v + 1; back[(size_t)c2] = v + 1; internal[(size_t)v] = 1;
         }
@@ -509,7 +509,7 @@ int preload_code_objects(int device) {
     if (std::find(done.begin(), done.end(), device) != done.end()) return LUTLDPC_OK;
     hipFuncAttributes a;
     HIP_TRY(hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&frame_state_kernel)));             // this translation unit
-    HIP_TRY((preload_fused<2, 0>())); HIP_TRY((preload_fused<2, 1>())); HIP_TRY((preload_fused<2, 2>()));
+    HIP_TRY((preload_fused<2, 0>())); HIP_TRY((preload_fused<2, 1>())); HIP_TRY((preload_fused<2, 2>())); HIP_TRY((preload_fused<2, 3>()));
     HIP_TRY((preload_vn_fast<TT_VAR, 1>())); HIP_TRY((preload_vn_fast<TT_VAR, 2>())); HIP_TRY((preload_vn_fast<TT_DEC, 2>()));
     HIP_TRY((preload_cn_fast<2>()));
     // the row permutation of the compaction uses 66 KB of dynamic LDS (kernels_compact.hpp)
@@ -966,7 +966,8 @@ int launch_fused_slot(lutldpc_decoder *d, const lutldpc_decoder::SkewPlan &plan,
                    reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p, d->d_msg0_t.p
     if (d->fused_bucket_id == 0) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 0>(FUSED_ARGS)));
     else if (d->fused_bucket_id == 1) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 1>(FUSED_ARGS)));
-    else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
+    else if (d->fused_bucket_id == 2) PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 2>(FUSED_ARGS)));
+    else PACK_DISPATCH(d, (lutldpc::launch_fused<PK, 3>(FUSED_ARGS)));
 #undef FUSED_ARGS
     LAUNCH_CHECK();
     if (d->validate) {                               // attribute a device fault to this launch
@@ -1410,6 +1411,8 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
         for (auto &c : d->cclass) max_cn = std::max(max_cn, c.deg);
         for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
         d->fused_bucket_id = std::max(0, fused_bucket(max_vn, max_cn));
+        // LUTLDPC_FUSED_BUCKET_MIN: run a code of small degrees through a wider bucket's kernel (measurement of what the bucket costs)
+        if (const char *e = getenv("LUTLDPC_FUSED_BUCKET_MIN")) { int v = atoi(e); if (v >= 0 && v < kFusedBuckets && fused_bucket_rank(v) > fused_bucket_rank(d->fused_bucket_id)) d->fused_bucket_id = v; }
     }
     d->device = device;
     if (device >= 0) { rc = upload_static(d.get()); if (rc) return rc; }

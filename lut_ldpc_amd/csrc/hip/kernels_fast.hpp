@@ -534,13 +534,20 @@ constexpr int kFusedMaxTables = 20;
 //   bucket 0: variable degrees <= 8,  check degrees <= 8   (64 VGPRs, 8 waves per SIMD)
 //   bucket 1:                  <= 12,               <= 16
 //   bucket 2:                  <= 20,               <= 32
-constexpr int kFusedBuckets = 3;
-constexpr int kFusedVnDeg[kFusedBuckets] = {8, 12, 20};
-constexpr int kFusedCnDeg[kFusedBuckets] = {8, 16, 32};
+//   bucket 3:                  <= 8,                <= 10   (added last, ranked second: kFusedBucketOrder)
+constexpr int kFusedBuckets = 4;
+constexpr int kFusedVnDeg[kFusedBuckets] = {8, 12, 20, 8};
+constexpr int kFusedCnDeg[kFusedBuckets] = {8, 16, 32, 10};
+// the bucket a code runs in: the leanest one that holds its degrees -- bucket 3 (variable degrees <= 8, check degrees <= 10, 8 waves
+// per SIMD like bucket 0 but with SGPR spills in the widest check bodies) sits between buckets 0 and 1: the irregular N = 64800
+// code of the reference has five checks of degree 9 among 32400 (+4.5 % over bucket 1, which runs 5 waves per SIMD)
+constexpr int kFusedBucketOrder[kFusedBuckets] = {0, 3, 1, 2};
 inline int fused_bucket(int max_vn_deg, int max_cn_deg) {
-    for (int b = 0; b < kFusedBuckets; b++) if (max_vn_deg <= kFusedVnDeg[b] && max_cn_deg <= kFusedCnDeg[b]) return b;
+    for (int b : kFusedBucketOrder) if (max_vn_deg <= kFusedVnDeg[b] && max_cn_deg <= kFusedCnDeg[b]) return b;
     return -1;
 }
+inline int fused_bucket_rank(int bucket) { for (int i = 0; i < kFusedBuckets; i++) if (kFusedBucketOrder[i] == bucket) return i; return -1; }
+inline constexpr int fused_max_cn_deg() { int m = 0; for (int b = 0; b < kFusedBuckets; b++) m = kFusedCnDeg[b] > m ? kFusedCnDeg[b] : m; return m; }
 
 struct RoleParams {
     int32_t kind;          // 0: min-sum check class, 1: variable class
@@ -578,7 +585,7 @@ __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, 
 // for the whole decode: the role is picked with a wave-uniform run-time index, its fields come in through scalar
 // loads as they are needed).  The kernel-argument segment stays a handful of pointers.
 template <int PACK, bool CHECK, int BUCKET>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BUCKET == 0 ? LUTLDPC_B0_WAVES_MIN : BUCKET == 1 ? 4 : 3, BUCKET == 0 ? LUTLDPC_B0_WAVES_MAX : 8))) void pass_fused_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BUCKET == 0 || BUCKET == 3) ? LUTLDPC_B0_WAVES_MIN : BUCKET == 1 ? 4 : 3, (BUCKET == 0 || BUCKET == 3) ? LUTLDPC_B0_WAVES_MAX : 8))) void pass_fused_kernel(
     const RoleParams *__restrict__ roles, const int2 *__restrict__ items, int prio, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx,
     const uint8_t *__restrict__ msg0)
@@ -792,7 +799,8 @@ hipError_t preload_fused() {
     X template void launch_fused<1, 0> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 0> LUTLDPC_FUSED_SIG; \
     X template void launch_fused<1, 1> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 1> LUTLDPC_FUSED_SIG; \
     X template void launch_fused<1, 2> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 2> LUTLDPC_FUSED_SIG; \
-    X template hipError_t preload_fused<2, 0>(); X template hipError_t preload_fused<2, 1>(); X template hipError_t preload_fused<2, 2>(); \
+    X template void launch_fused<1, 3> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 3> LUTLDPC_FUSED_SIG; \
+    X template hipError_t preload_fused<2, 0>(); X template hipError_t preload_fused<2, 1>(); X template hipError_t preload_fused<2, 2>(); X template hipError_t preload_fused<2, 3>(); \
     X template hipError_t preload_vn_fast<TT_VAR, 1>(); X template hipError_t preload_vn_fast<TT_VAR, 2>(); X template hipError_t preload_vn_fast<TT_DEC, 2>(); \
     X template hipError_t preload_cn_fast<2>();
 

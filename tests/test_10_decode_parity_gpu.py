@@ -151,9 +151,9 @@ def test_fewer_iterations_than_designed_is_rejected_unless_decision_set():
     dec.close()
 
 
-@pytest.mark.parametrize("K,M,dv,bucket", [(1600, 400, 3, 1), (3600, 400, 3, 2), (840, 420, 3, 0)])
+@pytest.mark.parametrize("K,M,dv,bucket", [(1600, 400, 3, 1), (3600, 400, 3, 2), (840, 420, 3, 0), (1120, 420, 3, 3)])
 def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket):
-    """Dual-diagonal codes with check degrees 14 (middle bucket), 29 (widest) and 8 (first): most zigzag nodes are updated
+    """Dual-diagonal codes with check degrees 14 (middle bucket), 29 (widest), 8 (first) and 10 (bucket 3): most zigzag nodes are updated
     inside the check pass in every bucket, one frame group and several, fixed work and early termination."""
     from helpers import write_ira_alist
     from oracle import oracle as orc
@@ -162,7 +162,7 @@ def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket):
     cd = orc.Codec(code, skip_rank=True)
     cd.set_rank(M)
     cd.rate = 1.0 - M / N
-    sig = {1: 0.52, 2: 0.40, 0: 0.62}[bucket]
+    sig = {1: 0.52, 2: 0.40, 0: 0.62, 3: 0.57}[bucket]
     cd.design_luts(sigma2=sig ** 2, max_iters=10, nq_msg=np.full(10, 16, np.int32), nq_cha=16)
     dec = product_decoder(cd)
     desc = dec.describe()
