@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU box (test infrastructure: uses the oracle as the checker, like tests/): random irregular
+graphs, alphabets, iteration counts, batch sizes and exit modes through the default path, every bit and iteration code
+against the oracle.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+import pathlib, sys, tempfile
+import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from helpers import awgn_labels, compare, product_decoder, write_random_alist     # noqa: E402
+from oracle import oracle as orc                                                   # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for c in range(cases):
+    N = int(rng.integers(200, 1600))
+    rate = float(rng.choice([0.5, 0.6, 0.75]))
+    M = max(40, int(N * (1 - rate)))
+    k = int(rng.integers(1, 4))
+    dvc = sorted(rng.choice([2, 3, 4, 5, 6, 8, 9, 12], size=k, replace=False).tolist())
+    if dvc == [2]:
+        dvc = [2, 3]
+    p = rng.dirichlet(np.ones(len(dvc)) * 2)
+    nqc, nqm = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
+    I = int(rng.integers(3, 12))
+    B = int(rng.choice([1, 63, 257, 513, 700, 1100, 1537]))
+    d = pathlib.Path(tempfile.mkdtemp())
+    try:
+        dv, dc = write_random_alist(d / "r.alist", N, M, dvc, p.tolist(), seed=1000 + c)
+    except AssertionError:
+        print(f"case {c}: graph generation gave up, skipped"); continue
+    if dc.max() > 32 or dv.max() > 20:
+        print(f"case {c}: degrees outside the compile-time kernels, skipped"); continue
+    code = orc.Code(d / "r.alist")
+    cd = orc.Codec(code, skip_rank=True); cd.set_rank(M); cd.rate = 1.0 - M / N
+    sig = float(rng.uniform(0.45, 0.9))
+    cd.design_luts(sigma2=sig ** 2, max_iters=I, nq_msg=np.full(I, nqm, np.int32), nq_cha=nqc)
+    dec = product_decoder(cd)
+    snr = -10 * np.log10(2 * cd.rate * sig * sig) + float(rng.uniform(-0.3, 1.5))
+    cha, msg, _ = awgn_labels(cd, B, snr, seed=c)
+    try:
+        for psc, pisc in [(True, True), (True, False), (False, False)]:
+            it = compare(cd, dec, cha, msg, psc, pisc)
+        print(f"case {c}: N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} nq={nqc}/{nqm} I={I} B={B} bucket={dec.describe()['fused_bucket']} ok, iteration codes {sorted(set(it.tolist()))[:5]}")
+    except AssertionError as e:
+        bad += 1
+        print(f"case {c}: MISMATCH N={N} M={M} dv={dvc} nq={nqc}/{nqm} I={I} B={B}: {str(e)[:200]}")
+    dec.close()
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
