@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU box (test infrastructure: uses the oracle as the checker, like tests/): random irregular
 graphs, alphabets, iteration counts, batch sizes and exit modes through the default path, every bit and iteration code
-against the oracle.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+against the oracle.  Usage: python tests/fuzz_parity.py [cases] [seed]"""
 import pathlib, sys, tempfile
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))   # (this file lives in tests/: only tests may use the oracle)
 from helpers import awgn_labels, compare, product_decoder, write_random_alist     # noqa: E402
 from oracle import oracle as orc                                                   # noqa: E402
 
