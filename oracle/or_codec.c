@@ -96,6 +96,10 @@ static void set_params(or_codec *c, int min_lut, int max_iters, const unsigned c
 double or_codec_design_luts(or_codec *c, const char *tree_method, int min_lut, double sigma2, int max_iters,
                             const unsigned char *reuse_vec, int Nq_Cha, const int *Nq_Msg, int allow_deg1)
 {
+    /* the reference stops here or shortly after: LDPC_DE.cpp:199 (no reuse in the first iteration), LDPC_Code_LUT.cpp:122
+     * (first and last iteration are exempt from tree reuse); a reused stage in the last iteration would also meet the
+     * two-label decision stage with the wrong alphabet */
+    if (max_iters < 1 || (reuse_vec && (reuse_vec[0] || reuse_vec[max_iters - 1]))) return -1;
     set_params(c, min_lut, max_iters, reuse_vec, Nq_Cha, Nq_Msg);
     or_ensemble *ens = or_empirical_ensemble(c->code);
     or_tree_array *var_t = NULL, *chk_t = NULL;

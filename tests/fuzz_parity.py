@@ -34,14 +34,28 @@ for c in range(cases):
     code = orc.Code(d / "r.alist")
     cd = orc.Codec(code, skip_rank=True); cd.set_rank(M); cd.rate = 1.0 - M / N
     sig = float(rng.uniform(0.45, 0.9))
-    cd.design_luts(sigma2=sig ** 2, max_iters=I, nq_msg=np.full(I, nqm, np.int32), nq_cha=nqc)
+    # one case in four each: check-node LUT trees instead of min-sum, a message alphabet that shrinks along the iterations,
+    # LUT stages reused over several iterations (src/LDPC_Code_LUT.cpp:120-169)
+    extra = {}
+    nq_vec = np.full(I, nqm, np.int32)
+    if rng.integers(4) == 0 and dc.max() <= 12:
+        extra["min_lut"] = False
+    if rng.integers(4) == 0 and nqm == 16 and I >= 4:
+        nq_vec[int(rng.integers(1, I - 1)):] = 8
+    if rng.integers(4) == 0:
+        reuse = rng.integers(0, 2, I).astype(np.int32); reuse[0] = 0; reuse[-1] = 0     # (first and last iteration are exempt: src/LDPC_Code_LUT.cpp:122)
+        for i in range(1, I):
+            if nq_vec[i] != nq_vec[i - 1]:
+                reuse[i] = 0
+        extra["reuse_vec"] = reuse.tolist()
+    cd.design_luts(sigma2=sig ** 2, max_iters=I, nq_msg=nq_vec, nq_cha=nqc, **extra)
     dec = product_decoder(cd)
     snr = -10 * np.log10(2 * cd.rate * sig * sig) + float(rng.uniform(-0.3, 1.5))
     cha, msg, _ = awgn_labels(cd, B, snr, seed=c)
     try:
         for psc, pisc in [(True, True), (True, False), (False, False)]:
             it = compare(cd, dec, cha, msg, psc, pisc)
-        print(f"case {c}: N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} nq={nqc}/{nqm} I={I} B={B} bucket={dec.describe()['fused_bucket']} ok, iteration codes {sorted(set(it.tolist()))[:5]}")
+        print(f"case {c}: N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} nq={nqc}/{nqm} I={I} B={B} bucket={dec.describe()['fused_bucket']} skew={dec.describe()['skewed_pipeline']} {extra if extra else ''} nq_msg={sorted(set(nq_vec.tolist()))} ok, iteration codes {sorted(set(it.tolist()))[:5]}")
     except AssertionError as e:
         bad += 1
         print(f"case {c}: MISMATCH N={N} M={M} dv={dvc} nq={nqc}/{nqm} I={I} B={B}: {str(e)[:200]}")

@@ -112,3 +112,22 @@ def test_design_cache_roundtrip(tmp_path, monkeypatch):
     assert not e.design_from_cache and e.var_trees_txt == fresh.var_trees_txt
     for x in (fresh, a, b, c, d, e):
         x.close()
+
+
+@pytest.mark.parametrize("reuse", [[0, 1, 0, 1], [1, 0, 0, 0]])
+def test_reuse_in_the_first_or_last_iteration_is_refused(reuse):
+    """src/LDPC_DE.cpp:199 and src/LDPC_Code_LUT.cpp:122 stop on a reuse vector that reuses in the first or last iteration: the
+    product returns an error, the oracle too (found by tests/fuzz_parity.py: the oracle used to run into the two-label decision
+    stage with a reused stage's alphabet)."""
+    import lut_ldpc_amd as L
+    from helpers import CODES
+    from oracle import oracle as orc
+    alist = CODES / "rate0.50_dv03_dc06_N1000.alist"
+    c = L.Codec(alist, known_rank=500, device=-1)
+    with pytest.raises(L.LutLdpcError):
+        c.design_luts(sigma2=0.7, max_iters=4, nq_cha=16, nq_msg=[16, 8, 8, 8], reuse_vec=reuse)
+    c.design_luts(sigma2=0.7, max_iters=4, nq_cha=16, nq_msg=[16, 8, 8, 8], reuse_vec=[0, 0, 1, 0])     # a valid one still works
+    cd = orc.Codec(orc.Code(alist), skip_rank=True)
+    cd.set_rank(500)
+    with pytest.raises(RuntimeError):
+        cd.design_luts(sigma2=0.7, max_iters=4, nq_msg=np.array([16, 8, 8, 8], np.int32), nq_cha=16, reuse_vec=reuse)
