@@ -361,6 +361,11 @@ int LDPC_DE_LUT::evolve(double thr, bool save_luts, LUT_Tree_Array &var_trees, L
 
 void LDPC_DE_LUT::get_lut_trees(LUT_Tree_Array &var_trees, LUT_Tree_Array &chk_trees, double sig) {
     if (reuse_vec[0]) throw std::invalid_argument("LDPC_DE_LUT::get_lut_trees(): reuse not possible for the initial iteration");
+    // a reused stage reads and writes the alphabets of the stage it repeats: the reference adds probability vectors of different
+    // lengths otherwise (src/LDPC_DE.cpp:434-487,505-557: an IT++ size assertion in a debug build, undefined in a release build)
+    for (int i = 1; i < maxiter_de; i++)
+        if (reuse_vec[(size_t)i] && (Nq_Msg_vec[(size_t)i] != Nq_Msg_vec[(size_t)i - 1] || (i + 1 < maxiter_de && Nq_Msg_vec[(size_t)i + 1] != Nq_Msg_vec[(size_t)i])))
+            throw std::invalid_argument("LDPC_DE_LUT::get_lut_trees(): a reused LUT stage must keep the message alphabets of the stage it repeats");
     (void)evolve(sig, true, var_trees, chk_trees);
 }
 

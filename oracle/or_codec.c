@@ -100,6 +100,10 @@ double or_codec_design_luts(or_codec *c, const char *tree_method, int min_lut, d
      * (first and last iteration are exempt from tree reuse); a reused stage in the last iteration would also meet the
      * two-label decision stage with the wrong alphabet */
     if (max_iters < 1 || (reuse_vec && (reuse_vec[0] || reuse_vec[max_iters - 1]))) return -1;
+    /* a reused stage reads and writes the alphabets of the stage it repeats (LDPC_DE.cpp:434-487,505-557 add probability
+     * vectors of different lengths otherwise) */
+    for (int i = 1; reuse_vec && i < max_iters; i++)
+        if (reuse_vec[i] && (Nq_Msg[i] != Nq_Msg[i - 1] || (i + 1 < max_iters && Nq_Msg[i + 1] != Nq_Msg[i]))) return -1;
     set_params(c, min_lut, max_iters, reuse_vec, Nq_Cha, Nq_Msg);
     or_ensemble *ens = or_empirical_ensemble(c->code);
     or_tree_array *var_t = NULL, *chk_t = NULL;

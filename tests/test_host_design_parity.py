@@ -114,11 +114,12 @@ def test_design_cache_roundtrip(tmp_path, monkeypatch):
         x.close()
 
 
-@pytest.mark.parametrize("reuse", [[0, 1, 0, 1], [1, 0, 0, 0]])
+@pytest.mark.parametrize("reuse", [[0, 1, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0]])
 def test_reuse_in_the_first_or_last_iteration_is_refused(reuse):
     """src/LDPC_DE.cpp:199 and src/LDPC_Code_LUT.cpp:122 stop on a reuse vector that reuses in the first or last iteration: the
     product returns an error, the oracle too (found by tests/fuzz_parity.py: the oracle used to run into the two-label decision
-    stage with a reused stage's alphabet)."""
+    stage with a reused stage's alphabet).  Third case: a reused stage across a change of the message alphabet (16 -> 8 after
+    iteration 0) -- the reference would add probability vectors of different lengths."""
     import lut_ldpc_amd as L
     from helpers import CODES
     from oracle import oracle as orc
