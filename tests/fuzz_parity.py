@@ -13,6 +13,7 @@ import os
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 COMPACT = "--compact" in sys.argv      # many frame groups, compaction of the surviving frames forced on with random check points
+BP = "--bp" in sys.argv                # the [BP] comparison decoder instead of the LUT decoder (GPU against the oracle's statement of it)
 bad = 0
 for c in range(cases):
     N = int(rng.integers(200, 1600))
@@ -45,6 +46,28 @@ for c in range(cases):
     if dc.max() > 32 or dv.max() > 20:
         print(f"case {c}: degrees outside the compile-time kernels, skipped"); continue
     code = orc.Code(d / "r.alist")
+    if BP:
+        import lut_ldpc_amd as L
+        dpar = [(12, 300, 7, 28), (12, 0, 7, 28), (8, 64, 4, 16), (10, 128, 5, 20)][int(draws[0][0])]
+        ref = orc.BP(code, *dpar)
+        gpu = L.BPDecoder(code.nvar, code.nchk, code.dv, code.dc, code.cn_msg_idx, *dpar, device=0)
+        Bb = min(B, 300)
+        r2 = np.random.default_rng(c)
+        N0 = 10 ** (-(2.0 + 4 * sig) / 10) / (1.0 - M / N)
+        llr = 4 * (1.0 + r2.normal(0.0, np.sqrt(N0 / 2), (Bb, N))) / N0
+        llr[0] = 9.0
+        okc = True
+        codes = None
+        for psc, pisc in [(True, True), (True, False), (False, False)]:
+            ref.set_exit_conditions(I + 8, psc, pisc); gpu.set_exit_conditions(I + 8, psc, pisc)
+            wb, wi, wq = ref.decode_llr_batch(llr)
+            gb, gi, gq = gpu.decode_llr_batch(llr, want_qllr=True)
+            okc = okc and bool((gi == wi).all() and (gq == wq).all() and (gb == wb).all())
+            codes = codes if codes is not None else sorted(set(wi.tolist()))
+        gpu.close()
+        bad += 0 if okc else 1
+        print(f"case {c}: BP N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} d={dpar} B={Bb} iters<={I + 8} {'ok' if okc else 'MISMATCH'}, return codes with the syndrome test {codes[:8]}", flush=True)
+        continue
     cd = orc.Codec(code, skip_rank=True); cd.set_rank(M); cd.rate = 1.0 - M / N
     # one case in four each: check-node LUT trees instead of min-sum, a message alphabet that shrinks along the iterations,
     # LUT stages reused over several iterations (src/LDPC_Code_LUT.cpp:120-169)
