@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -301,6 +302,11 @@ bool LDPC_Code_LUT::load_design(const std::string &path, const std::string &key,
 
 void LDPC_Code_LUT::store_design(const std::string &path, const std::string &key) const {
     const std::string tmp = path + ".tmp" + std::to_string((long long)::getpid());
+    {
+        std::error_code ec;                                     // a fresh checkout has no cache directory yet
+        const auto dir = std::filesystem::path(path).parent_path();
+        if (!dir.empty()) std::filesystem::create_directories(dir, ec);
+    }
     {
         std::ofstream o(tmp, std::ios::binary);
         if (!o) return;                                      // an unwritable cache directory only costs the next start its design
