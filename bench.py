@@ -179,6 +179,38 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def oracle_codec_for(cd, max_iter, psc, pisc):
+    """The oracle (oracle/: CPU restatement of the reference decoder) loaded with the product's tables, handed over as the
+    reference's own tree text.  Checker only: called after the timed regions."""
+    from oracle import oracle as orc
+    code = orc.Code(ROOT / "data" / "codes" / f"{cd.alist}.alist")
+    oc = orc.Codec(code, skip_rank=True)
+    nq = np.full(max_iter, cd.nq_msg, np.int32)
+    oc.set_trees_txt(cd.var_trees_txt, "" if cd.min_lut else cd.chk_trees_txt, max_iter, np.zeros(max_iter, np.uint8), cd.nq_cha, nq, cd.min_lut)
+    oc.set_exit_conditions(max_iter, psc, pisc)
+    return oc
+
+
+def outcome_sample(it, n, I):
+    """n frames covering every kind of outcome of an as-shipped decode: failed, passed on the channel decisions, early exits over
+    the range of iteration counts, full count -- drawn from the whole batch (both halves, every frame group)."""
+    rng = np.random.default_rng(5)
+    pos = it[(it > 0) & (it < I)]
+    cuts = np.unique(np.percentile(pos, [0, 25, 50, 75, 100])) if len(pos) else np.array([1, I])
+    groups = [np.flatnonzero(it < 0), np.flatnonzero(it == 0), np.flatnonzero(it == I)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        groups.append(np.flatnonzero((it >= lo) & (it <= hi) & (it > 0) & (it < I)))
+    idx = []
+    for g in groups:
+        if len(g):
+            idx += list(rng.choice(g, size=min(len(g), max(1, n // len(groups))), replace=False))
+    idx = list(dict.fromkeys(int(i) for i in idx))[:n]
+    rest = np.setdiff1d(np.arange(len(it)), idx)
+    if len(idx) < n and len(rest):
+        idx += list(rng.choice(rest, size=min(len(rest), n - len(idx)), replace=False))
+    return np.array(sorted(idx))
+
+
 def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=9.0):
     """SURVEY 8(d), both CPU legs, on bounded samples of the same labels on this host's cores:
     (i) the oracle in FAITHFUL mode -- the reference's structure (per-output queue copy + recursive tree walk, one
@@ -491,6 +523,22 @@ def main():
                                 "frames_that_left_through_the_exit_test": int((it_s > 0).sum().item()),
                                 "note": "parity_check_iter = true (exit test every iteration, finished frames retired by compaction), "
                                         "same decoder, labels resident in HBM"}
+        if rank == 0 and not args.no_cpu_baseline:
+            # the as-shipped result against the oracle under psc = pisc = 1: a sample over every kind of outcome, from the
+            # whole batch (this is the path every batch of BASELINE config 4 takes: chain fusion + compaction + late decided bits)
+            it_h = it_s.cpu().numpy()
+            idx = outcome_sample(it_h, 64, max_iter)
+            sel = torch.from_numpy(idx).cuda()
+            oc = oracle_codec_for(cd, max_iter, True, True)
+            t1 = time.perf_counter()
+            wb, wi = oc.lut_decode_batch_flat(cha_s[sel].cpu().numpy(), msg_s[sel].cpu().numpy(), threads=usable_cores())
+            same = bool((wi == it_h[idx]).all() and (wb == bits_s[sel].cpu().numpy()).all())
+            result["as_shipped"].update({"gpu_matches_oracle_on_sample": same, "frames_compared_with_oracle": int(len(idx)),
+                                         "sample_outcomes": {"failed": int((wi < 0).sum()), "passed_on_channel_decisions": int((wi == 0).sum()),
+                                                             "early_exit": int(((wi > 0) & (wi < max_iter)).sum()), "full_count": int((wi == max_iter).sum())},
+                                         "oracle_s": time.perf_counter() - t1, "compaction_active": bool(0 < dec.describe().get("compaction_min_groups", -1) <= (B + dec.describe()["tile_frames"] - 1) // dec.describe()["tile_frames"])})
+            if not same:
+                raise SystemExit("as-shipped GPU output differs from the oracle on the sample")
         cd.set_exit_conditions(max_iter, psc, psc)
         del cha_s, msg_s, bits_s
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

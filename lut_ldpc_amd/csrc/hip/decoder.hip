@@ -605,14 +605,44 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(d->d_frame_of.alloc((size_t)Bpad)); HIP_TRY(d->d_perm.alloc((size_t)Bpad)); HIP_TRY(d->d_tmp3.alloc((size_t)Bpad * 3));
     HIP_TRY(d->d_ctl.alloc(8)); HIP_TRY(d->d_slot_of.alloc((size_t)Bpad)); HIP_TRY(d->d_iters_tmp.alloc((size_t)Bpad));
     HIP_TRY(d->d_grp.alloc(G));
+    // Every row exists with a defined content from the start: with the first check pass reading the initial-message rows
+    // (first_from_nodes) the edge rows of PAD frames and of frames that passed the test on the channel decisions are never
+    // written while their group still has active frames, and the variable passes compute on all lanes (results masked).
+    HIP_TRY(hipMemsetAsync(d->d_msgs.p, 0, d->d_msgs.bytes(), d->stream));
+    HIP_TRY(hipMemsetAsync(d->d_hard.p, 0, d->d_hard.bytes(), d->stream));
+    HIP_TRY(hipMemsetAsync(d->d_cha_t.p, 0, d->d_cha_t.bytes(), d->stream));
+    HIP_TRY(hipMemsetAsync(d->d_msg0_t.p, 0, d->d_msg0_t.bytes(), d->stream));
     d->Bcap = Bpad;
     return LUTLDPC_OK;
 }
 
+// Always on, O(1), before every decode: the batch buffers every kernel addresses rows in exist and hold Bpad frames.  (The one
+// device fault this library has shown was a valid edge row off a NULL message base)
+int check_batch_buffers(const lutldpc_decoder *d, int Bpad) {
+    const size_t G = (size_t)(Bpad / d->tile());
+    auto bad = [&](const char *what) { return fail(LUTLDPC_ERR_STATE, std::string("batch buffer check failed before the decode: ") + what); };
+    if (Bpad <= 0 || Bpad > d->Bcap || Bpad % d->tile()) return bad("batch larger than the allocation");
+    if (!d->d_msgs.p || d->d_msgs.n < G * (size_t)d->E * kRowBytes) return bad("message rows");
+    if (!d->d_cha_t.p || d->d_cha_t.n < G * (size_t)d->nvar * kRowBytes) return bad("channel rows");
+    if (!d->d_msg0_t.p || d->d_msg0_t.n < G * (size_t)d->nvar * kRowBytes) return bad("initial-message rows");
+    if (!d->d_hard.p || d->d_hard.n < G * (size_t)d->nvar * kRowBytes) return bad("decided-bit rows");
+    if (!d->d_state.p || d->d_state.n < (size_t)Bpad || !d->d_iters.p || d->d_iters.n < (size_t)Bpad) return bad("frame state");
+    if (!d->d_vfail.p || d->d_vfail.n < (size_t)d->Bcap * kVfailSlots * 2) return bad("flag buffers");
+    if (!d->d_fast_idx.p || !d->d_tables.p || !d->stream) return bad("static tables / stream");
+    return LUTLDPC_OK;
+}
+
+// LUTLDPC_VALIDATE=1: additionally wait for the launch(es) just issued, so that a device fault is reported by the launch site
+// that caused it (function and line), whatever the kernel -- not only the fused ones (no graph capture in that mode)
 #define LAUNCH_CHECK()                                                                              \
     do {                                                                                            \
         hipError_t e_ = hipGetLastError();                                                          \
         if (e_ != hipSuccess) return fail(LUTLDPC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+        if (d->validate) {                                                                          \
+            e_ = hipStreamSynchronize(d->stream);                                                   \
+            if (e_ == hipSuccess) e_ = hipGetLastError();                                           \
+            if (e_ != hipSuccess) return fail(LUTLDPC_ERR_HIP, std::string("launch failed on the device (") + __func__ + ":" + std::to_string(__LINE__) + "): " + hipGetErrorString(e_)); \
+        }                                                                                           \
     } while (0)
 
 // instantiate a launch for the decoder's packing
@@ -1142,7 +1172,19 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
     if (d->pisc) {   // :275-279
-        if ((rc = launch_syndrome_of_labels(d, G))) return rc;
+        if (is_pow2(d->Nq_Cha / 2)) {
+            if ((rc = launch_syndrome_of_labels(d, G))) return rc;
+        } else {
+            // the decided bit `label < Nq_Cha/2` is the inverted sign BIT of the label only when Nq_Cha/2 is a power of two: any other
+            // channel alphabet goes through decided-bit rows (SWAR compare) and the parity pass over them
+            {
+                Timed t(d, LUTLDPC_K_LAYOUT);
+                const size_t n_words = (size_t)G * (size_t)N * kRowBytes / 4;
+                PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_kernel<PK>, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, n_words, d->Nq_Cha / 2));
+                LAUNCH_CHECK();
+            }
+            if ((rc = launch_syndrome(d, G))) return rc;
+        }
         if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
         {   // decided bits of the frames that passed = signs of their channel labels (:275); groups without such a frame return at once
             Timed t(d, LUTLDPC_K_LAYOUT);
@@ -1202,6 +1244,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
 // plainly and fills the item-table cache, whose uploads may not happen inside a capture).  Short codes
 // are launch-bound, for them this is worth ~20 %.  Off while kernel events are being recorded.
 int decode_tiles(lutldpc_decoder *d, int B) {
+    if (int rc = check_batch_buffers(d, d->bpad(B))) return rc;
     if (!d->use_graph || d->profiling) return decode_tiles_launch(d, B);
     const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
     if (d->graphs.size() > 32 && !d->graphs.count(key)) d->drop_graphs();      // callers with ever-changing batch sizes: bound the cache
@@ -1306,7 +1349,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
+    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"compaction_min_groups\":" << [&] { for (int G = 1; G <= 2 * kPermuteMaxGroups; G++) if (compaction_on(d, G)) return G; return -1; }() << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 

@@ -226,7 +226,11 @@ void LDPC_Code_LUT::set_exit_conditions(int max_iters_in, bool syndr_check_each_
 // (operator<< of Array<Array<LUT_Tree>>, src/LUT_Tree.cpp:847-865) -- the same strings save_code writes into lut_codec.it.
 // Off unless the variable is set (the design parity tests always design).
 namespace {
-const char *kDesignCacheTag = "lutldpc-design-cache-1";
+// format tag + a hash of the design sources of THIS build (csrc/Makefile: design_src_hash.inc): a file written by a build whose
+// design code differed is a foreign file and is ignored
+const char *kDesignCacheTag = "lutldpc-design-cache-2-"
+#include "design_src_hash.inc"
+    ;
 
 struct Fnv {
     uint64_t h = 1469598103934665603ull;
@@ -315,7 +319,8 @@ void LDPC_Code_LUT::store_design(const std::string &path, const std::string &key
         o << "map " << Nq_Cha_2_Nq_Msg_map.size();
         for (int x : Nq_Cha_2_Nq_Msg_map) o << ' ' << x;
         o << '\n';
-        const std::string v = to_string(var_trees), c = minLUT ? std::string() : to_string(chk_trees);
+        // (chk_trees: with min_lut the fresh design leaves the check templates in place -- a cache hit must leave the same object behind)
+        const std::string v = to_string(var_trees), c = chk_trees.empty() ? std::string() : to_string(chk_trees);
         o << "var_trees " << v.size() << '\n' << v << '\n' << "chk_trees " << c.size() << '\n' << c << '\n' << "end\n";
         if (!o) { o.close(); std::remove(tmp.c_str()); return; }
     }

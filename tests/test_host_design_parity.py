@@ -102,6 +102,11 @@ def test_design_cache_roundtrip(tmp_path, monkeypatch):
     assert b.design_from_cache
     assert b.var_trees_txt == fresh.var_trees_txt and (b.qb_cha == fresh.qb_cha).all() and (b.qb_msg == fresh.qb_msg).all()
     assert (b.cha2msg_map == fresh.cha2msg_map).all()
+    # a cache hit leaves the same object behind as a fresh design: the codec files are byte-identical (min_lut = true here:
+    # the check templates a fresh design keeps are restored too)
+    fresh.save(tmp_path / "fresh.it"); b.save(tmp_path / "hit.it")
+    assert (tmp_path / "fresh.it").read_bytes() == (tmp_path / "hit.it").read_bytes()
+    assert b.chk_trees_txt == fresh.chk_trees_txt
     c = product_codec("reg36_n1000_q3_chklut")            # other alphabets, CHKTREE designs
     assert not c.design_from_cache and len(list(tmp_path.glob("*.lutdesign"))) == 2
     d = product_codec("reg36_n1000_q3_chklut")
