@@ -1,0 +1,84 @@
+// kernels_resident.hpp -- device helpers of the LDS-RESIDENT decoder (jit_resident.hpp generates the kernel around them).
+//
+// A code whose edge messages fit the 160 KB of LDS of one compute unit -- E * 4 bytes per SET of 8 frames (nibble labels) --
+// is decoded without touching HBM between the channel labels and the decided bits: one workgroup owns S sets, keeps their E
+// edge messages in LDS as dwords (eight nibble frames or four byte frames per dword: the same per-lane format as one lane of
+// a 256-byte row of the streaming kernels, kernels_common.hpp), and runs ALL iterations (src/LDPC_Code_LUT.cpp:301-338) with
+// workgroup barriers between the passes.  A thread handles one (set, node) item per round: the arithmetic of an item is the
+// arithmetic one LANE of the streaming kernels does (same SWAR min-sum, same frame-by-frame tree look-ups), only the
+// operands come from LDS instead of rows in HBM and the node indices are per lane instead of wave-uniform.
+// This header is embedded into the library as text and prepended to the generated source (like kernels_common.hpp).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace lutldpc {
+
+// Min-sum check update on the packed labels of one check (src/LDPC_Code_LUT.cpp:355-402): x[k] = dword of edge k (8 nibble
+// frames / 4 byte frames), r[k] = extrinsic output.  Same arithmetic as cn_minsum_body (kernels_fast.hpp): sign bit `sbit`
+// doubles as the flag bit of every comparison, min1 / min2 running, output magnitude = (mag == min1 ? min2 : min1).
+// Returns the parity of the negative inputs in bit `sbit` of every element (the check's syndrome bit per frame).
+template <int DEG, int PACK>
+__device__ __forceinline__ uint32_t res_minsum(const uint32_t (&x)[DEG], uint32_t (&r)[DEG], int sbit, uint32_t SB, uint32_t LOW) {
+    constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;
+    const uint32_t odd = (DEG & 1) ? SB : 0u;
+    uint32_t min1 = LOW, min2 = LOW, spp = 0;
+    uint32_t mg[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const uint32_t xh = x[k];
+        const uint32_t pos = xh & SB;
+        const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
+        const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
+        spp ^= xh;
+        mg[k] = mag;
+        if (k == 0) {
+            min1 = mag;
+        } else {
+            const uint32_t g1 = ((mag | SB) - min1) & SB;         // mag >= min1
+            const uint32_t k1 = g1 - (g1 >> sbit);
+            const uint32_t lo = bfi(k1, min1, mag);
+            const uint32_t hi = mag ^ min1 ^ lo;
+            if (k == 1) {
+                min2 = hi;
+            } else {
+                const uint32_t g2 = ((min2 | SB) - hi) & SB;      // min2 >= hi
+                const uint32_t k2 = g2 - (g2 >> sbit);
+                min2 = bfi(k2, hi, min2);
+            }
+            min1 = lo;
+        }
+    }
+    const uint32_t tn = (spp ^ odd) & SB;
+    const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const uint32_t eq = ~(((mg[k] ^ min1) | SB) - ONE) & SB;
+        const uint32_t ke = eq - (eq >> sbit);
+        const uint32_t mc = bfi(ke, m2c, m1c);
+        const uint32_t po = (tn ^ x[k]) & SB;
+        const uint32_t kp = po - (po >> sbit);
+        r[k] = (mc ^ kp) | po;
+    }
+    return tn;
+}
+
+// 0x1 in every element (nibble / byte) of a packed label dword whose value is < t (any t up to the alphabet size): the
+// decided bit of a label, src/LDPC_Code_LUT.cpp:275
+template <int PACK>
+__device__ __forceinline__ uint32_t res_lt(uint32_t x, uint32_t t) {
+    uint32_t r[PACK];
+#pragma unroll
+    for (int h = 0; h < PACK; h++) r[h] = swar_lt(unpack_half<PACK>(x, h), t);
+    return pack_halves<PACK>(r);
+}
+
+// element mask (0xF / 0xFF per frame) from one flag bit per element
+template <int PACK>
+__device__ __forceinline__ uint32_t res_mask(uint32_t one_bits) { return one_bits * (PACK == 2 ? 0xFu : 0xFFu); }
+
+// frame offset inside its set of element n of a dword (kernels_common.hpp: low nibbles of bytes 0..3 = frames 0..3, high
+// nibbles = frames 4..7; byte rows: byte b = frame b)
+template <int PACK>
+__device__ __forceinline__ int res_frame_of_element(int n) { return PACK == 2 ? ((n & 1) * 4 + (n >> 1)) : n; }
+
+}  // namespace lutldpc

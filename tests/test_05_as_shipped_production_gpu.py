@@ -92,13 +92,15 @@ def test_dvbs2_as_shipped_at_production_batch_size():
     for f in clean:                                            # pass the test on the channel decisions, in both halves
         cha[f] = cd.nq_cha - 1
         msg[f] = cd.nq_msg[0] - 1
+    noisy = np.arange(40, B, 175)                              # 24 frames well below the design point: they fail (negative count)
+    cha[noisy], msg[noisy], _ = awgn_labels(cd, len(noisy), 0.6, seed=778)
     dec.set_exit_conditions(50, True, True)
     runs = [dec.lut_decode_batch(cha, msg) for _ in range(3)]  # plain launches, capture + replay, replay
     bits, it = runs[0]
     for b, i in runs[1:]:
         assert (i == it).all() and (b == bits).all()
     assert (it[clean] == 0).all() and (it == 0).sum() == len(clean)
-    assert (it < 0).sum() > 0 and ((it > 0) & (it < 40)).sum() > 0 and (it == 50).sum() >= 0
+    assert (it[noisy] < 0).sum() > 0 and ((it > 0) & (it < 40)).sum() > 0
     hist = np.bincount(it[it > 0], minlength=51)
     assert (hist > 0).sum() > 8, hist                          # frames leave over many iterations: the compaction has work to do
     assert bits[it >= 0].sum() == 0                            # all-zero codeword sent; a frame reported converged is a codeword
