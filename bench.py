@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- decoded codewords/s of the MI355X LUT-LDPC decode path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dvbs2|twin|c2|c1|c5|c5chk] [--batch B] [--mode fixed|shipped]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dvbs2|twin|c2|c1|c5|c5chk] [--batch B] [--mode fixed|shipped] [--no-configs]
 
 A *step* is one pass of the hot path (LDPC_Code_LUT::lut_decode, all iterations) over one batch of
 B frames per GPU whose quantised labels are already resident in HBM.  Default workload: the
@@ -20,7 +20,10 @@ stream while the same K steps are issued once more as plain launches right after
 the error counting around the decode (the whole loop of LDPC_BER_Sim::sim_snr_point); `as_shipped` is the
 same decoder with the reference's default exit test on (parity_check_iter = true), a few extra steps.
 `cpu_baseline` times the oracle (oracle/, the CPU restatement of the reference decoder) on a bounded
-sample of the same workload on this host -- the oracle is used only there.
+sample of the same workload on this host -- the oracle is used only there.  `configs` (default run, one GPU) times the other
+BASELINE.json configurations as well -- (3,6) N=10000 at batch 4096, (6,32) N=2048 with both check updates, the N=64800 twin,
+the N=500 example code -- each with its throughput in both exit modes, the dominant kernel with its mean launch time from HIP
+events, the roofline fraction recomputed from SURVEY 8(d)'s bytes, and an oracle check of a sample.
 """
 from __future__ import annotations
 
@@ -248,6 +251,95 @@ def cpu_baseline(cd, cha, msg, max_iter, psc, budget_s=9.0):
             "sample": flat["sample"] + f"; nproc = {cores}", "faithful_1core": faithful, "flat_allcores": flat}, bits, iters, fb, fi
 
 
+def algorithmic_bytes_per_frame(E, N, I, b):
+    """bytes = 4 I E b + (I + 2) N b + N / 8 (b bytes per stored label; I executed iterations)"""
+    return (4 * I * E + (I + 2) * N) * b + N / 8
+
+
+KERNEL_OF_KIND = {"resident": "lutldpc_jit_pass (generated LDS-resident decode: all iterations in one launch)",
+                  "fused_pass": "pass_fused_kernel (check pass of one half-batch + variable pass of the other)",
+                  "cn_pass": "check pass", "vn_pass": "variable pass", "decision": "decision pass", "syndrome": "syndrome_bits_kernel",
+                  "layout": "transposes / state", "frontend": "sampler + error count"}
+
+
+def quick_config(L, torch, wl, B, device, steps=4, oracle_frames=32):
+    """One of the other BASELINE configurations: throughput on HBM-resident labels in both exit modes, the dominant kernel with its
+    mean launch duration (HIP events on the decoder's stream, plain launches after the timed region), the roofline fraction of
+    the whole decode from SURVEY 8(d)'s bytes, and an oracle check of a sample of each mode's output."""
+    alist, sigma, max_iter, qc, qm, B_default, extra, known_rank = WORKLOADS[wl]
+    B = B or B_default
+    t_all = time.perf_counter()
+    cd = L.Codec(ROOT / "data" / "codes" / f"{alist}.alist", known_rank=known_rank, device=device)
+    cd.alist, cd.nq_cha, cd.nq_msg = alist, 1 << qc, 1 << qm
+    cd.design_luts(sigma2=sigma * sigma, max_iters=max_iter, nq_cha=1 << qc, nq_msg=1 << qm, **extra)
+    cd.min_lut = bool(extra.get("min_lut", True))
+    qmap = None
+    if wl.startswith("c5"):
+        cd.set_initial_message_mode(1)
+        qmap = np.asarray(cd.cha2msg_map, np.uint8)
+    N, E = cd.nvar, cd.nedges
+    out = {"workload": f"{alist}, {qc}-bit channel / {qm}-bit messages, {max_iter} iterations, {'min-LUT' if cd.min_lut else 'CHKTREE check update'}",
+           "frames_per_step": B, "N": N, "E": E}
+    bits = torch.empty((B, N), dtype=torch.uint8, device="cuda")
+    its = torch.empty(B, dtype=torch.int32, device="cuda")
+    for mode, psc in (("fixed", False), ("as_shipped", True)):
+        snr = -10 * np.log10(2 * cd.rate * sigma * sigma) + (0.4 if psc else 0.0)
+        cd.set_exit_conditions(max_iter, psc, psc)
+        dec = cd.decoder()
+        cha, msg = make_labels_device(cd, B, snr, seed=777 + psc, qcha_map=qmap)
+
+        def step(sync):
+            dec.lut_decode_batch_device(cha.data_ptr(), msg.data_ptr(), B, bits.data_ptr(), its.data_ptr(), sync=sync)
+        for _ in range(3):                                   # plain launches, graph capture, first replay
+            step(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k == steps - 1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        it_h = its.cpu().numpy()
+        it_eff = float(np.abs(it_h).mean()) if psc else float(max_iter)
+        b_msg = float(dec.describe()["message_bytes"])
+        entry = {"value": B / dt, "unit": "codewords/s", "ms_per_step": dt * 1e3, "EbN0_dB": round(float(snr), 3), "mean_iterations_executed": it_eff}
+        if not psc:
+            dec.set_profiling(True); dec.reset_profile()
+            step(True)
+            prof = {k: v for k, v in dec.profile().items() if v["launches"]}
+            dec.set_profiling(False)
+            kind = max(prof, key=lambda k: prof[k]["ms"])
+            name = KERNEL_OF_KIND.get(kind, kind)
+            if kind in ("cn_pass", "vn_pass"):
+                cls = dec.describe()["cn_classes" if kind == "cn_pass" else "vn_classes"]
+                name = f"{cls[0]['kernel']} ({name})"
+            bpf = algorithmic_bytes_per_frame(E, N, max_iter, b_msg)
+            entry.update({"dominant_kernel": name, "dominant_kernel_avg_launch_ms": prof[kind]["ms"] / prof[kind]["launches"],
+                          "dominant_kernel_launches_per_step": prof[kind]["launches"], "dominant_kernel_share_of_kernel_time": prof[kind]["ms"] / sum(v["ms"] for v in prof.values()),
+                          "kernel_ms_per_step": {k: v["ms"] for k, v in prof.items()},
+                          "roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": bpf, "bytes_per_label": b_msg, "achieved": bpf * (B / dt) / 1e9, "peak": HBM_PEAK_GBPS,
+                                       "unit": "GB/s", "frac": bpf * (B / dt) / 1e9 / HBM_PEAK_GBPS,
+                                       "note": ("messages stay in LDS for the whole decode: the HBM traffic is the labels in and the bits out; the fraction is the "
+                                                "canonical SURVEY 8(d) bytes over the decode time, comparable with the streaming kernels" if kind == "resident" else
+                                                "SURVEY 8(d) bytes of the whole decode over its wall time")}})
+        # oracle check on a sample (psc: every kind of outcome), after the timed region
+        idx = outcome_sample(it_h, oracle_frames, max_iter) if psc else np.arange(min(B, oracle_frames))
+        sel = torch.from_numpy(idx).cuda()
+        oc = oracle_codec_for(cd, max_iter, psc, psc)
+        wb, wi = oc.lut_decode_batch_flat(cha[sel].cpu().numpy(), msg[sel].cpu().numpy(), threads=usable_cores())
+        entry["gpu_matches_oracle_on_sample"] = bool((wi == it_h[idx]).all() and (wb == bits[sel].cpu().numpy()).all())
+        entry["frames_compared_with_oracle"] = int(len(idx))
+        out[mode] = entry
+        del cha, msg
+    out["resident_decoder"] = bool(dec.describe().get("resident", 0))
+    out["seconds"] = time.perf_counter() - t_all
+    cd.close()
+    del bits, its
+    torch.cuda.empty_cache()
+    if not (out["fixed"]["gpu_matches_oracle_on_sample"] and out["as_shipped"]["gpu_matches_oracle_on_sample"]):
+        raise SystemExit(f"configs[{wl}]: GPU output differs from the oracle on the sample")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +356,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--as-shipped-steps", type=int, default=3, help="extra untimed-for-`value` steps with the exit test on (0 = skip; fixed mode only)")
     ap.add_argument("--frame-loop-steps", type=int, default=2, help="extra untimed-for-`value` steps of the full sampler+decode+count loop (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations; default run on one GPU only)")
     args = ap.parse_args()
 
     import torch
@@ -413,18 +506,20 @@ def main():
     del src_buf, dst_buf
     # HBM bytes per pass from the PMC counters (collected in separate rocprofv3 --pmc passes and
     # committed under profiles/; valid only for the workload/batch/mode they were taken on)
+    # (a counter set counts only when it was taken on THIS build of the library -- the build stamp of describe() -- otherwise null)
+    build_stamp = dec.describe().get("build")
     traffic = None
     for f in sorted((ROOT / "profiles").glob("*pmc_traffic*.json"), reverse=True):
         t = json.loads(f.read_text())
-        if t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
-            traffic = t.get("fused_pass_hbm_bytes_per_launch" if fu["launches"] else "vn_pass_hbm_bytes_per_pass")
+        if t.get("build") == build_stamp and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
+            traffic = t.get("fused_pass_hbm_bytes_per_launch" if fu["launches"] else "resident_hbm_bytes_per_launch" if prof.get("resident", {}).get("launches") else "vn_pass_hbm_bytes_per_pass")
             break
     # what limits the dominant kernel on the chip besides HBM (SQ counters collected by tools/profile_round.sh in their own
     # rocprofv3 --pmc passes, summarised by tools/pmc_limiter.py and committed under profiles/; same validity rule)
     limiter = None
     for f in sorted((ROOT / "profiles").glob("*pmc_limiter*.json"), reverse=True):
         t = json.loads(f.read_text())
-        if t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode:
+        if t.get("build") == build_stamp and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode:
             limiter = {"valu_busy": t["valu_busy"], "lds_busy": t["lds_busy"],
                        "lds_bank_conflict_share_of_lds_cycles": t["lds_bank_conflict_share_of_lds_cycles"],
                        "hbm_share_of_achievable_6p3TBps": None, "source": f.name,
@@ -448,10 +543,19 @@ def main():
                 "frac": fu_bytes / (fu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": fu_bytes, "avg_launch_ms": fu_ms, "launches": fu["launches"],
                 "bytes_not_moved_thanks_to_chain_fusion_per_launch": saved,
-                "achieved_after_fusion_GBps": (fu_bytes - saved) / (fu_ms * 1e-3) / 1e9}
+                "achieved_after_fusion_GBps": (fu_bytes - saved) / (fu_ms * 1e-3) / 1e9,
+                # the HBM utilisation proper: bytes really moved (PMC traffic of this build when there is one, else canonical - fused)
+                "frac_of_bytes_moved": (traffic if traffic else fu_bytes - saved) / (fu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if limiter is not None:
             limiter["hbm_share_of_achievable_6p3TBps"] = ((traffic if traffic else fu_bytes - saved) / (fu_ms * 1e-3) / 1e9) / 6300.0
             roof["limiter"] = limiter
+    elif prof.get("resident", {}).get("launches"):
+        rs_ms = prof["resident"]["ms"] / prof["resident"]["launches"]
+        bpf = algorithmic_bytes_per_frame(E, N, it_eff, b_msg)
+        roof = {"bound": "hbm", "kernel": KERNEL_OF_KIND["resident"], "achieved": bpf * B / (rs_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": bpf * B / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": bpf * B, "avg_launch_ms": rs_ms,
+                "launches": prof["resident"]["launches"],
+                "note": "messages stay in LDS for the whole decode: the launch moves only labels in and bits out through HBM; the fraction prices the canonical SURVEY 8(d) bytes"}
     else:
         roof = {"bound": "hbm", "kernel": "vn_pass", "achieved": vn_bytes / (vn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": vn_bytes / (vn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
@@ -541,6 +645,14 @@ def main():
                 raise SystemExit("as-shipped GPU output differs from the oracle on the sample")
         cd.set_exit_conditions(max_iter, psc, psc)
         del cha_s, msg_s, bits_s
+    configs = None
+    if rank == 0 and world == 1 and args.workload == "dvbs2" and not args.no_configs:
+        # the headline decoder's buffers (7 GB at 32768 frames) go first; its outputs are kept for the oracle check below
+        keep_bits, keep_iters = out_bits[:n_host].cpu().numpy(), out_iters[:n_host].cpu().numpy()
+        configs = {}
+        for wl, Bc in (("c2", 4096), ("c5", 32768), ("c5chk", 32768), ("c1", 16384), ("twin", 32768)):
+            configs[wl] = quick_config(L, torch, wl, Bc, local)
+    result["configs"] = configs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ob, oi, fb, fi = cpu_baseline(cd, cha_h, msg_h, max_iter, psc)
         n, nf = len(oi), len(fi)

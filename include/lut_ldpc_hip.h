@@ -155,7 +155,8 @@ void *lutldpc_decoder_stream(lutldpc_decoder *d);
 #define LUTLDPC_K_LAYOUT    4   /* transposes / edge initialisation / state update */
 #define LUTLDPC_K_FRONTEND  5   /* channel sampler + error counting                */
 #define LUTLDPC_K_FUSED_PASS 6  /* skewed pipeline: check pass of one half + variable pass of the other */
-#define LUTLDPC_K_COUNT     7
+#define LUTLDPC_K_RESIDENT  7   /* LDS-resident decode: all iterations of a batch in one launch */
+#define LUTLDPC_K_COUNT     8
 
 /* When enabled every launch is bracketed by HIP events recorded on the decoder's stream. */
 int lutldpc_decoder_set_profiling(lutldpc_decoder *d, int enable);
@@ -188,6 +189,8 @@ int lutldpc_selftest_program_stats(lutldpc_decoder *d, int kind, int set, int cl
  * source is also compiled for gfx950 with hiprtc (no device needed); a failure returns LUTLDPC_ERR_HIP and
  * leaves the compiler log in lutldpc_last_error(). */
 int64_t lutldpc_selftest_jit_source(lutldpc_decoder *d, int kind, int set, int cls, char *buf, int64_t cap, int compile);
+/* source of the LDS-resident decode kernel for a batch of G frame groups (info: sets per workgroup, threads, LDS bytes) */
+int64_t lutldpc_selftest_resident_source(lutldpc_decoder *d, int G, char *buf, int64_t cap, int compile, int32_t *info);
 
 #ifdef __cplusplus
 }

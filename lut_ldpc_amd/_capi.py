@@ -16,7 +16,7 @@ if os.environ.get("LUTLDPC_LIB"):          # A/B runs of two builds of the same 
 
 OK, ERR_ARG, ERR_PARSE, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = 0, -1, -2, -3, -4, -5
 K_CN_PASS, K_VN_PASS, K_DECISION, K_SYNDROME, K_LAYOUT, K_FRONTEND, K_FUSED_PASS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
-KIND_NAMES = ["cn_pass", "vn_pass", "decision", "syndrome", "layout", "frontend", "fused_pass"]
+KIND_NAMES = ["cn_pass", "vn_pass", "decision", "syndrome", "layout", "frontend", "fused_pass", "resident"]
 
 
 class LutLdpcError(RuntimeError):
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "lutldpc_selftest_program_eval": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int]),
     "lutldpc_selftest_program_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),
     "lutldpc_selftest_jit_source": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int]),
+    "lutldpc_selftest_resident_source": (C.c_int64, [_vp, C.c_int, C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
     if hasattr(lib, _name):

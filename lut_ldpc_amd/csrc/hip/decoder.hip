@@ -12,6 +12,7 @@
 #include "kernels_compact.hpp"
 #include "lut_program.hpp"
 #include "jit.hpp"
+#include "jit_resident.hpp"
 
 namespace lutldpc { LUTLDPC_FAST_LAUNCHERS(extern) }     // instantiated in fast_*.hip / fused.hip
 
@@ -89,6 +90,14 @@ struct lutldpc_decoder {
     TreeArray var_trees, chk_trees;
     // ---- programs: [set][class]
     std::vector<std::vector<Program>> var_prog, chk_prog, dec_prog;
+    // the same trees after exact table composition (lut_program.hpp: compose_tree): fewer, larger look-ups; used by the generated
+    // LDS-resident kernel.  *_tab_c: {offset, bytes} of the class blob inside all_tables.  LUTLDPC_COMPOSE=0: off (the originals).
+    std::vector<std::vector<Program>> var_prog_c, chk_prog_c, dec_prog_c;
+    std::vector<std::vector<std::pair<int, int>>> var_tab_c, chk_tab_c, dec_tab_c;
+    // Measured on MI355X (tools/resident_probe.py): a 4 KB table spreads its 1024 dwords over 32 banks 32 deep -- the three-input
+    // look-ups run into 3-4-way bank conflicts where a 256-byte table has at most two dwords per bank -- and the halved look-up
+    // count does not pay for it: (3,6) N=10000 1.72 -> 1.24 M codewords/s with composition.  Off by default; LUTLDPC_COMPOSE=1.
+    int use_compose = 0, compose_space = 4096;
     std::vector<Op> all_ops;
     std::vector<uint8_t> all_tables;
     std::vector<PassPlan> var_plan, chk_plan, dec_plan;   // per tree set
@@ -99,6 +108,7 @@ struct lutldpc_decoder {
     std::vector<int32_t> fast_idx;
     std::vector<int> vn_idx_off, cn_idx_off;                      // per class
     std::vector<int> cn_nidx_off;                                 // per check class: the NODE of every entry of the edge table (iteration 0 reads the initial-message rows)
+    std::vector<int> cn_tidx_off, cn_tnidx_off, vn_tidx_off;      // transposed tables of the LDS-resident decoder: [k][node] edges / nodes per check class, [2][node] {node id, first edge} per variable class
     int first_from_nodes = 1;                                     // LUTLDPC_FIRST_FROM_NODES=0: copy the initial messages to the edge rows first (init_edges_kernel)
     // chain fusion (build_fast_index): per check class the offset of its {back, forward} node table (-1 = no links),
     // per variable class the dense table / count of the nodes NOT updated inside the check pass
@@ -139,6 +149,14 @@ struct lutldpc_decoder {
     int compact_keep = 1;                                           // LUTLDPC_COMPACT_KEEP: the frames that left keep their rows, bits recovered once at the end
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     DevBuf<int32_t> d_grp;                           // per frame group: every frame failed the probe of the test on the channel decisions
+    // LDS-resident decoder (jit_resident.hpp): codes whose edge messages fit the LDS of a compute unit are decoded by ONE generated
+    // kernel per decode -- all iterations inside, no HBM traffic between the labels and the decided bits.  LUTLDPC_RESIDENT=0: off
+    // (the streaming kernels run instead); LUTLDPC_RESIDENT_S / _NT force the sets per workgroup / threads per workgroup.
+    int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0;
+    bool resident_ok = false;
+    struct ResidentPlan { int S = 0, NT = 0, lds = 0; const JitKernel *k = nullptr; };
+    std::map<int, ResidentPlan> resident_plans;       // by frame groups
+    std::string resident_log;
     int use_jit = 1;            // tree-specialised kernels for shapes the compile-time path does not cover (jit.hpp)
     // (the loaded kernels live in a process-wide registry keyed by device + source text, see jit_registry(): decoders share
     // them and they are never unloaded)
@@ -363,6 +381,29 @@ void build_fast_index(lutldpc_decoder *d) {
             for (size_t j = 0; j < cnt; j++) d->fast_idx.push_back(edge_node[(size_t)d->fast_idx[off + j]]);
         }
     }
+    // LDS-resident decoder (jit_resident.hpp): there a LANE owns a node, so the tables are transposed -- [k][node of the class] --
+    // and 64 lanes reading entry k of 64 consecutive nodes touch 256 contiguous bytes.  Canonical edge order of the check
+    // (ascending variable node, as cn_msg_idx: a CHKTREE consumes its inputs in that order).
+    {
+        std::vector<int> edge_node((size_t)d->E, 0);
+        for (int v = 0; v < d->nvar; v++)
+            for (int e = d->vn_ptr[(size_t)v]; e < d->vn_ptr[(size_t)v + 1]; e++) edge_node[(size_t)e] = v;
+        d->cn_tidx_off.assign(d->cclass.size(), 0); d->cn_tnidx_off.assign(d->cclass.size(), 0); d->vn_tidx_off.assign(d->vclass.size(), 0);
+        for (size_t ci = 0; ci < d->cclass.size(); ci++) {
+            const auto &c = d->cclass[ci];
+            const size_t n = c.nodes.size();
+            d->cn_tidx_off[ci] = (int)d->fast_idx.size();
+            for (int k = 0; k < c.deg; k++) for (size_t j = 0; j < n; j++) d->fast_idx.push_back(d->cn_msg_idx[(size_t)(d->cn_ptr[(size_t)c.nodes[j]] + k)]);
+            d->cn_tnidx_off[ci] = (int)d->fast_idx.size();
+            for (int k = 0; k < c.deg; k++) for (size_t j = 0; j < n; j++) d->fast_idx.push_back(edge_node[(size_t)d->cn_msg_idx[(size_t)(d->cn_ptr[(size_t)c.nodes[j]] + k)]]);
+        }
+        for (size_t vi = 0; vi < d->vclass.size(); vi++) {
+            const auto &c = d->vclass[vi];
+            d->vn_tidx_off[vi] = (int)d->fast_idx.size();
+            for (int v : c.nodes) d->fast_idx.push_back(v);
+            for (int v : c.nodes) d->fast_idx.push_back(d->vn_ptr[(size_t)v]);
+        }
+    }
     // variable passes that follow a chained check pass skip the nodes it already updated
     for (size_t vi = 0; vi < d->vclass.size(); vi++) {
         if (d->vclass[vi].deg != 2) continue;
@@ -398,6 +439,21 @@ int validate_fast_index(const lutldpc_decoder *d) {
                 if (v < 0 || v >= d->nvar || e < 0 || e + c.deg > d->E) return bad("reduced variable class entry out of range");
             }
         }
+    }
+    for (size_t i = 0; i < d->vclass.size() && i < d->vn_tidx_off.size(); i++) {
+        const auto &c = d->vclass[i];
+        const size_t off = (size_t)d->vn_tidx_off[i], m = c.nodes.size();
+        if (off + 2 * m > n) return bad("transposed variable class table outside the blob");
+        for (size_t j = 0; j < m; j++) {
+            const int v = d->fast_idx[off + j], e = d->fast_idx[off + m + j];
+            if (v < 0 || v >= d->nvar || e < 0 || e + c.deg > d->E) return bad("transposed variable class entry out of range");
+        }
+    }
+    for (size_t i = 0; i < d->cclass.size() && i < d->cn_tidx_off.size(); i++) {
+        const auto &c = d->cclass[i];
+        const size_t cnt = c.nodes.size() * (size_t)c.deg, eo = (size_t)d->cn_tidx_off[i], no = (size_t)d->cn_tnidx_off[i];
+        if (eo + cnt > n || no + cnt > n) return bad("transposed check class table outside the blob");
+        for (size_t j = 0; j < cnt; j++) if (d->fast_idx[eo + j] < 0 || d->fast_idx[eo + j] >= d->E || d->fast_idx[no + j] < 0 || d->fast_idx[no + j] >= d->nvar) return bad("transposed check class entry out of range");
     }
     for (size_t i = 0; i < d->cclass.size(); i++) {
         const auto &c = d->cclass[i];
@@ -467,10 +523,27 @@ int compile_all(lutldpc_decoder *d) {
         }
         return build_plan(d, cls, &progs, &op_off, &tab_off, plan);
     };
+    // composed variants of the programs of one set (tables appended to the same blob)
+    auto add_composed = [&](const std::vector<Tree> &trees, const std::vector<NodeClass> &cls, int kind, std::vector<Program> &progs,
+                            std::vector<std::pair<int, int>> &tabs) -> int {
+        progs.assign(cls.size(), Program()); tabs.assign(cls.size(), {0, 0});
+        for (size_t i = 0; i < cls.size(); i++) {
+            const Tree &t = trees[(size_t)cls[i].tree_class];
+            const Tree tc = d->use_compose ? compose_tree(t, kind, (uint64_t)d->compose_space) : compose_tree(t, kind, 0);
+            std::string e;
+            if (!compile_program(tc, kind, cls[i].deg, progs[i], e)) return fail(LUTLDPC_ERR_UNSUPPORTED, "composed tree, degree " + std::to_string(cls[i].deg) + ": " + e);
+            progs[i].node_tabs.clear();                         // (they point into the temporary tree)
+            tabs[i] = {(int)d->all_tables.size(), (int)progs[i].tables.size()};
+            d->all_tables.insert(d->all_tables.end(), progs[i].tables.begin(), progs[i].tables.end());
+        }
+        return LUTLDPC_OK;
+    };
     size_t ns = (size_t)n_sets;
     d->var_prog.assign(ns, {}); d->dec_prog.assign(ns, {}); d->chk_prog.assign(ns, {});
     d->var_plan.assign(ns, {}); d->dec_plan.assign(ns, {}); d->chk_plan.assign(ns, {});
     d->var_fast.assign(ns, {}); d->dec_fast.assign(ns, {});
+    d->var_prog_c.assign(ns, {}); d->dec_prog_c.assign(ns, {}); d->chk_prog_c.assign(ns, {});
+    d->var_tab_c.assign(ns, {}); d->dec_tab_c.assign(ns, {}); d->chk_tab_c.assign(ns, {});
     for (size_t s = 0; s < ns; s++) {
         // a set is either message-update trees or (the last one) decision trees
         int type = d->var_trees[s].empty() ? TT_VAR : d->var_trees[s][0].type;
@@ -479,6 +552,10 @@ int compile_all(lutldpc_decoder *d) {
         else rc = add_set(d->var_trees[s], d->vclass, TT_VAR, d->var_prog[s], d->var_plan[s], &d->var_fast[s]);
         if (rc) return rc;
         if (!d->min_lut) { rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s], nullptr); if (rc) return rc; }
+        if (type == TT_DEC) rc = add_composed(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog_c[s], d->dec_tab_c[s]);
+        else rc = add_composed(d->var_trees[s], d->vclass, TT_VAR, d->var_prog_c[s], d->var_tab_c[s]);
+        if (rc) return rc;
+        if (!d->min_lut && (rc = add_composed(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog_c[s], d->chk_tab_c[s]))) return rc;
     }
     if (d->min_lut) { int rc = build_plan(d, d->cclass, nullptr, nullptr, nullptr, d->cn_minsum_plan); if (rc) return rc; }
     return LUTLDPC_OK;
@@ -1161,6 +1238,152 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
     return LUTLDPC_OK;
 }
 
+// ----------------------------------------------------------------------------- LDS-resident decoder (jit_resident.hpp)
+constexpr int kLdsPerCu = 160 * 1024, kResidentCus = 256;
+
+ResidentSpec resident_spec(const lutldpc_decoder *d, int S, int NT) {
+    ResidentSpec R;
+    R.pack = d->pack; R.N = d->nvar; R.E = d->E; R.S = S; R.NT = NT; R.I = d->max_iters_created; R.nq_cha = d->Nq_Cha; R.min_lut = d->min_lut;
+    R.nq_msg = d->Nq_Msg; R.iter_set = d->iter_set; R.U = d->resident_U;
+    for (size_t i = 0; i < d->vclass.size(); i++) R.vcls.push_back({d->vclass[i].deg, (int)d->vclass[i].nodes.size(), d->vn_tidx_off[i], 0});
+    for (size_t i = 0; i < d->cclass.size(); i++) R.ccls.push_back({d->cclass[i].deg, (int)d->cclass[i].nodes.size(), d->cn_tidx_off[i], d->cn_tnidx_off[i]});
+    const size_t ns = d->var_plan.size();
+    R.var_prog.assign(ns, {}); R.dec_prog.assign(ns, {}); R.chk_prog.assign(ns, {});
+    R.var_tab.assign(ns, {}); R.dec_tab.assign(ns, {}); R.chk_tab.assign(ns, {});
+    for (size_t s = 0; s < ns; s++) {
+        auto fill = [&](const PassPlan &plan, const std::vector<Program> &progs, const std::vector<std::pair<int, int>> &tabs, std::vector<const Program *> &pp,
+                        std::vector<std::pair<int, int>> &tt) {
+            if (!plan.valid) return;
+            for (size_t c = 0; c < progs.size(); c++) { pp.push_back(&progs[c]); tt.push_back(tabs[c]); }
+        };
+        fill(d->var_plan[s], d->var_prog_c[s], d->var_tab_c[s], R.var_prog[s], R.var_tab[s]);
+        fill(d->dec_plan[s], d->dec_prog_c[s], d->dec_tab_c[s], R.dec_prog[s], R.dec_tab[s]);
+        if (!d->min_lut) fill(d->chk_plan[s], d->chk_prog_c[s], d->chk_tab_c[s], R.chk_prog[s], R.chk_tab[s]);
+    }
+    return R;
+}
+
+// can this code be decoded out of LDS at all (one set per workgroup)?
+bool resident_eligible(const lutldpc_decoder *d) {
+    if (!d->use_resident || !d->use_jit || !d->use_fast || d->device < 0) return false;
+    if (d->min_lut) for (int nq : d->Nq_Msg) if (!is_pow2(nq / 2)) return false;
+    for (auto &c : d->cclass) if (c.deg < 2 || c.deg > 64) return false;
+    // wide CHKTREE checks (a 31-leaf tree: 184 look-ups per frame and check, inputs / outputs / edge ids of 32 edges in registers) run
+    // faster through the streaming pass kernels: (6,32) N=2048 with min_lut = false 7.4 M codewords/s against 5.6 M out of LDS
+    if (!d->min_lut && d->use_resident < 2) for (auto &c : d->cclass) if (c.deg > 16) return false;      // (LUTLDPC_RESIDENT=2 forces it)
+    for (auto &c : d->vclass) if (c.deg > 24) return false;
+    if (d->vclass.size() > 12 || d->cclass.size() > 12) return false;
+    const ResidentSpec R = resident_spec(d, 1, 1024);
+    return resident_lds_bytes(R) <= kLdsPerCu - 2048;
+}
+
+// Sets per workgroup and workgroup size for a batch of G frame groups: the cheapest of the configurations that fit.
+// Model (fitted to tools/resident_probe.py runs on MI355X): a compute unit holds as many workgroups as LDS (S * E dwords + tables)
+// and the register file (estimated registers per thread) allow; several small workgroups per compute unit beat one large one
+// (their check and variable phases interleave: (6,32) N=2048 23.6 M codewords/s at S = 1 / 512 threads against 19.0 M at S = 2 /
+// 1024), few waves per compute unit hide the LDS latency badly, and every pass of a workgroup costs two barriers and a table
+// staging whatever its size (N=500: S = 8 beats S = 2 by 1.5x).
+bool resident_pick(const lutldpc_decoder *d, int G, int &S_out, int &NT_out, int &lds_out) {
+    int max_vn = 0, max_cn = 0;
+    for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
+    for (auto &c : d->cclass) max_cn = std::max(max_cn, c.deg);
+    const long long sets = 64ll * G;
+    const int F = 4 * d->pack;
+    // work of one item in instruction-equivalents (look-ups from the node programs of tree set 0)
+    std::vector<double> wv(d->vclass.size()), wc(d->cclass.size());
+    double wmax = 0;
+    for (size_t i = 0; i < d->vclass.size(); i++) {
+        size_t ops = 0;
+        for (size_t s = 0; s < d->var_prog_c.size() && !ops; s++) if (i < d->var_prog_c[s].size()) ops = d->var_prog_c[s][i].ops.size();
+        wv[i] = F * (2.0 * d->vclass[i].deg + 1 + 2.0 * (double)ops) + 3.0 * d->vclass[i].deg + 20;
+        wmax = std::max(wmax, wv[i]);
+    }
+    for (size_t i = 0; i < d->cclass.size(); i++) {
+        size_t ops = 0;
+        if (!d->min_lut) for (size_t s = 0; s < d->chk_prog_c.size() && !ops; s++) if (i < d->chk_prog_c[s].size()) ops = d->chk_prog_c[s][i].ops.size();
+        const int dg = d->cclass[i].deg;
+        wc[i] = d->min_lut ? (dg <= 16 ? 16.0 * dg : 30.0 * dg) + 16 : F * (3.0 * dg + 2.5 * (double)ops) + 4.0 * dg;
+        wmax = std::max(wmax, wc[i]);
+    }
+    double best = 1e300; bool found = false;
+    for (int NT : {1024, 768, 512, 256}) {
+        if (d->resident_force_NT && NT != d->resident_force_NT) continue;
+        for (int S = 1; S <= 64; S++) {
+            if (d->resident_force_S && S != d->resident_force_S) continue;
+            const ResidentSpec R = resident_spec(d, S, NT);
+            const int lds = resident_lds_bytes(R);
+            if (lds > kLdsPerCu - 2048) break;
+            const int ipt = (int)((S * (long long)d->nvar + NT - 1) / NT) + (int)d->vclass.size();
+            if (ipt > 46) break;
+            const double vgpr = 30 + 3.0 * ipt + 2.0 * max_vn + (d->min_lut ? (max_cn <= 16 ? 3.0 * max_cn : 16.0) : 3.0 * max_cn);
+            int waves_simd = std::min(8, (int)(512.0 / vgpr));
+            if (NT == 1024 && vgpr <= 140) waves_simd = std::max(waves_simd, 4);       // __launch_bounds__(1024) holds the compiler to 128 registers
+            const int threads_cu = std::min(2048, waves_simd * 256);
+            if (NT > threads_cu && !(d->resident_force_NT || d->resident_force_S)) continue;
+            const int bpc = std::max(1, std::min(kLdsPerCu / (lds + 512), threads_cu / NT));
+            double W = 0;
+            for (size_t i = 0; i < d->vclass.size(); i++) W += S * (double)d->vclass[i].nodes.size() * wv[i];
+            for (size_t i = 0; i < d->cclass.size(); i++) W += S * (double)d->cclass[i].nodes.size() * wc[i];
+            std::vector<int> a, b; int tvb, tcb;
+            resident_table_bytes(R, a, tvb, b, tcb);
+            const double load = W / NT + wmax + 350.0 + 2.0 * (tvb + tcb) / 4.0 / NT;     // per pass pair: imbalance, barriers, staging
+            const long long blocks = (sets + S - 1) / S;
+            const long long rounds = (blocks + (long long)kResidentCus * bpc - 1) / ((long long)kResidentCus * bpc);
+            const double waves = (double)bpc * NT / 64.0, util = std::min(1.0, 0.4 + waves / 40.0) * (bpc >= 2 ? 1.0 : 0.85);
+            const double t = (double)rounds * bpc * load / util;
+            if (t < best) { best = t; S_out = S; NT_out = NT; lds_out = lds; found = true; }
+        }
+    }
+    return found;
+}
+
+bool resident_active(const lutldpc_decoder *d) { return d->resident_ok && d->use_resident; }
+
+int resident_plan_for(lutldpc_decoder *d, int G, lutldpc_decoder::ResidentPlan **out) {
+    auto it = d->resident_plans.find(G);
+    if (it == d->resident_plans.end()) {
+        lutldpc_decoder::ResidentPlan pl;
+        if (!resident_pick(d, G, pl.S, pl.NT, pl.lds)) return fail(LUTLDPC_ERR_STATE, "resident decoder: no configuration fits");
+        // equal (S, NT) of another batch size: the same kernel
+        for (auto &kv : d->resident_plans) if (kv.second.S == pl.S && kv.second.NT == pl.NT) pl.k = kv.second.k;
+        if (!pl.k) {
+            std::string src, err;
+            if (!jit_resident_source(resident_spec(d, pl.S, pl.NT), src, err)) return fail(LUTLDPC_ERR_UNSUPPORTED, "resident decoder: " + err);
+            JitRegistry &reg = jit_registry();
+            std::lock_guard<std::mutex> lock(reg.mu);
+            const std::string key = std::to_string(d->device) + "\n" + src;
+            auto kt = reg.by_src.find(key);
+            if (kt == reg.by_src.end()) {
+                if (reg.by_src.size() >= kJitRegistryMax) return fail(LUTLDPC_ERR_STATE, "generated-kernel registry full");
+                std::vector<char> code;
+                JitKernel k;
+                std::string log;
+                if (!jit_compile(src, code, log) || !jit_load(code, k, log)) { d->resident_log = log; reg.by_src[key] = JitKernel(); return fail(LUTLDPC_ERR_HIP, "resident decoder: hiprtc / module load failed: " + log.substr(0, 2000)); }
+                kt = reg.by_src.emplace(key, k).first;
+            }
+            if (!kt->second.ok()) return fail(LUTLDPC_ERR_HIP, "resident decoder: kernel unavailable (earlier compile failure)");
+            pl.k = &kt->second;
+        }
+        it = d->resident_plans.emplace(G, pl).first;
+    }
+    *out = &it->second;
+    return LUTLDPC_OK;
+}
+
+int launch_resident(lutldpc_decoder *d, int G) {
+    lutldpc_decoder::ResidentPlan *pl = nullptr;
+    if (int rc = resident_plan_for(d, G, &pl)) return rc;
+    Timed t(d, LUTLDPC_K_RESIDENT);
+    ResidentArgs A{};
+    A.cha = d->d_cha_t.p; A.msg0 = d->d_msg0_t.p; A.hard = d->d_hard.p; A.state = d->d_state.p; A.iters = d->d_iters.p;
+    A.tables = d->d_tables.p; A.idx = d->d_fast_idx.p; A.n_sets = 64 * G; A.max_iters = d->max_iters; A.psc = d->psc; A.pisc = d->pisc;
+    void *args[] = {&A};
+    const unsigned blocks = (unsigned)((64 * G + pl->S - 1) / pl->S);
+    HIP_TRY(hipModuleLaunchKernel(pl->k->fn, blocks, 1, 1, (unsigned)pl->NT, 1, 1, 0, d->stream, args, nullptr));
+    LAUNCH_CHECK();
+    return LUTLDPC_OK;
+}
+
 // Core: decode the B frames whose labels are already in tile layout (d_cha_t / d_msg0_t).
 // Leaves the decided bits in d_hard (tile layout) and the iteration codes in d_iters.
 int decode_tiles_launch(lutldpc_decoder *d, int B) {
@@ -1171,6 +1394,11 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     if (!d->dec_plan[(size_t)last_set].valid)
         return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
+    if (resident_active(d)) {                     // the whole of lut_decode in one launch, messages in LDS (jit_resident.hpp)
+        if ((rc = launch_resident(d, G))) return rc;
+        if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
+        return LUTLDPC_OK;
+    }
     if (d->pisc) {   // :275-279
         if (is_pow2(d->Nq_Cha / 2)) {
             if ((rc = launch_syndrome_of_labels(d, G))) return rc;
@@ -1245,6 +1473,10 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
 // are launch-bound, for them this is worth ~20 %.  Off while kernel events are being recorded.
 int decode_tiles(lutldpc_decoder *d, int B) {
     if (int rc = check_batch_buffers(d, d->bpad(B))) return rc;
+    if (resident_active(d)) {                     // generate / compile / load outside any stream capture
+        lutldpc_decoder::ResidentPlan *pl = nullptr;
+        if (int rc = resident_plan_for(d, d->bpad(B) / d->tile(), &pl)) return rc;
+    }
     if (!d->use_graph || d->profiling) return decode_tiles_launch(d, B);
     const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
     if (d->graphs.size() > 32 && !d->graphs.count(key)) d->drop_graphs();      // callers with ever-changing batch sizes: bound the cache
@@ -1349,7 +1581,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"compaction_min_groups\":" << [&] { for (int G = 1; G <= 2 * kPermuteMaxGroups; G++) if (compaction_on(d, G)) return G; return -1; }() << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
+    o << "],\"resident\":" << (resident_active(d) ? 1 : 0) << ",\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"compaction_min_groups\":" << [&] { for (int G = 1; G <= 2 * kPermuteMaxGroups; G++) if (compaction_on(d, G)) return G; return -1; }() << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
     d->describe = o.str();
 }
 
@@ -1431,6 +1663,12 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_FIRST_FROM_NODES")) d->first_from_nodes = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CN_EDGES_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= 65536) { d->cn_edges_per_wave = v; d->cn_edges_from_env = true; } }
     if (const char *e = getenv("LUTLDPC_JIT")) d->use_jit = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_COMPOSE")) d->use_compose = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_COMPOSE_SPACE")) { int v = atoi(e); if (v >= 0 && v <= 65536) d->compose_space = v; }
+    if (const char *e = getenv("LUTLDPC_RESIDENT")) { int v = atoi(e); d->use_resident = v >= 2 ? 2 : v ? 1 : 0; }
+    if (const char *e = getenv("LUTLDPC_RESIDENT_S")) { int v = atoi(e); if (v >= 1 && v <= 64) d->resident_force_S = v; }
+    if (const char *e = getenv("LUTLDPC_RESIDENT_NT")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) d->resident_force_NT = v; }
+    if (const char *e = getenv("LUTLDPC_RESIDENT_U")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) d->resident_U = v; }
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_KEEP")) d->compact_keep = atoi(e) ? 1 : 0;
@@ -1459,6 +1697,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     }
     d->device = device;
     if (device >= 0) { rc = upload_static(d.get()); if (rc) return rc; }
+    d->resident_ok = resident_eligible(d.get());
     make_describe(d.get());
     *out = d.release();
     return LUTLDPC_OK;
@@ -1637,8 +1876,11 @@ int64_t lutldpc_decoder_device_bytes(lutldpc_decoder *d) {
 }
 const char *lutldpc_decoder_describe(lutldpc_decoder *d) { return d ? d->describe.c_str() : ""; }
 
+// kind + 16: the program of the same tree after table composition (compose_tree)
 static const Program *find_prog(lutldpc_decoder *d, int kind, int set, int cls) {
-    auto &v = kind == TT_VAR ? d->var_prog : kind == TT_CHK ? d->chk_prog : d->dec_prog;
+    const bool comp = (kind & 16) != 0;
+    kind &= 15;
+    auto &v = comp ? (kind == TT_VAR ? d->var_prog_c : kind == TT_CHK ? d->chk_prog_c : d->dec_prog_c) : (kind == TT_VAR ? d->var_prog : kind == TT_CHK ? d->chk_prog : d->dec_prog);
     if (set < 0 || set >= (int)v.size() || cls < 0 || cls >= (int)v[(size_t)set].size()) return nullptr;
     return &v[(size_t)set][(size_t)cls];
 }
@@ -1673,6 +1915,24 @@ int64_t lutldpc_selftest_jit_source(lutldpc_decoder *d, int kind, int set, int c
         std::vector<char> code;
         std::string log;
         if (!jit_compile(src, code, log)) return fail(LUTLDPC_ERR_HIP, "hiprtc: " + log);
+    }
+    if (buf && cap > (int64_t)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+    return (int64_t)src.size() + 1;
+}
+
+// Source of the LDS-resident decode kernel for a batch of G frame groups (jit_resident.hpp); compile != 0 also runs hiprtc (no
+// device needed).  info (optional, 3 ints): sets per workgroup, threads per workgroup, LDS bytes.  Works on host-only handles.
+int64_t lutldpc_selftest_resident_source(lutldpc_decoder *d, int G, char *buf, int64_t cap, int compile, int32_t *info) {
+    if (!d || G < 1) return fail(LUTLDPC_ERR_ARG, "NULL decoder / bad G");
+    int S = 0, NT = 0, lds = 0;
+    if (!resident_pick(d, G, S, NT, lds)) return fail(LUTLDPC_ERR_UNSUPPORTED, "resident decoder: the code does not fit the LDS");
+    std::string src, err;
+    if (!jit_resident_source(resident_spec(d, S, NT), src, err)) return fail(LUTLDPC_ERR_UNSUPPORTED, "resident decoder: " + err);
+    if (info) { info[0] = S; info[1] = NT; info[2] = lds; }
+    if (compile) {
+        std::vector<char> code;
+        std::string log;
+        if (!jit_compile(src, code, log)) return fail(LUTLDPC_ERR_HIP, "hiprtc: " + log.substr(0, 4000));
     }
     if (buf && cap > (int64_t)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
     return (int64_t)src.size() + 1;

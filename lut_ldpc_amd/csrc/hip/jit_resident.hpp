@@ -44,6 +44,7 @@ static_assert(sizeof(ResidentArgs) <= 128, "kernel arguments stay small (DESIGN.
 struct ResidentClass { int deg = 0, n = 0, idx_off = 0, nidx_off = 0; };
 struct ResidentSpec {
     int pack = 2, N = 0, E = 0, S = 1, NT = 1024, I = 0, nq_cha = 16, min_lut = 1;
+    int U = 0;                                               // frames per trip of the look-up loops (0: 2 up to degree 8, else 1)
     std::vector<int> nq_msg, iter_set;                       // per iteration
     std::vector<ResidentClass> vcls, ccls;
     // [set][class]: program (null: the set has none of this kind) and {offset, bytes} of the class blob in the table blob
@@ -202,10 +203,13 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
       << "    constexpr int PACK = " << PACK << ", BITS = " << BITS << ", F = 4 * PACK, S = " << S << ", NT = " << NT << ", E = " << E << ", N = " << N << ", I = " << I << ";\n"
       << "    constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;\n"
       << "    constexpr uint32_t NZC = " << R.nq_cha / 2 << "u;\n"
-      << "    __shared__ __attribute__((aligned(16))) uint32_t M[S * E];\n"
-      << "    __shared__ __attribute__((aligned(16))) uint8_t TV[" << std::max(tv_bytes, 16) << "];\n"
-      << "    __shared__ __attribute__((aligned(16))) uint8_t TC[" << std::max(tc_bytes, 16) << "];\n"
-      << "    __shared__ uint32_t L_fail[S], L_act[S];\n"
+      // one LDS block with the tables FIRST: their addresses are small constants that fold into the 16-bit offset field of
+      // ds_read_u8 (behind 120 KB of messages every look-up paid a v_add_u32 for its table base: a third of the VALU work)
+      << "    constexpr int TVB = " << std::max(tv_bytes, 16) << ", TCB = " << std::max(tc_bytes, 16) << ";\n"
+      << "    __shared__ __attribute__((aligned(16))) uint32_t LDS_ALL[(TVB + TCB) / 4 + 2 * S + S * E];\n"
+      << "    uint8_t *const TV = reinterpret_cast<uint8_t *>(LDS_ALL);\n    uint8_t *const TC = TV + TVB;\n"
+      << "    uint32_t *const L_fail = LDS_ALL + (TVB + TCB) / 4, *const L_act = L_fail + S;\n"
+      << "    uint32_t *const M = L_act + S;\n"
       << "    (void)I; (void)N; (void)TC;\n";
     // ---- per-iteration / per-set constants
     {
@@ -252,36 +256,67 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
         o << "    auto stage_chk = [&](int set) { for (int c = 0; c < " << NCC << "; c++) stage(TC + kTcOff[c], kChkOff[set * " << NCC << " + c], kChkLen[set * " << NCC << " + c]); };\n";
 
     // ---- persistent variable-node items: class c, round r
-    struct Item { int c, r; std::string sfx; };
+    // Items are dealt over the threads as ONE sequence of slots, heaviest class first: slot g = base(class) + item index belongs to
+    // thread g mod NT, so the partly filled last round of a class is completed by the first items of the next one (a class of 52
+    // degree-17 nodes otherwise occupies one wave for a whole pass while the others wait at the barrier).
+    struct Item { int c, r, base; std::string sfx; };
     std::vector<Item> items;
-    for (size_t c = 0; c < NVC; c++) {
-        const int rounds = (S * R.vcls[c].n + NT - 1) / NT;
-        for (int r = 0; r < rounds; r++) items.push_back({(int)c, r, "_" + S_((long long)c) + "_" + S_(r)});
+    {
+        std::vector<size_t> order(NVC);
+        for (size_t c = 0; c < NVC; c++) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return R.vcls[a].deg > R.vcls[b].deg; });
+        int base = 0;
+        for (size_t c : order) {
+            const int cnt = S * R.vcls[c].n;
+            for (int r = base / NT; cnt > 0 && r <= (base + cnt - 1) / NT; r++) items.push_back({(int)c, r, base, "_" + S_((long long)c) + "_" + S_(r)});
+            base += cnt;
+        }
     }
     if (items.size() > 48) { err = "more than 48 variable-node items per thread"; return false; }
-    for (auto &it : items) o << "    uint32_t cha" << it.sfx << " = 0u, hard" << it.sfx << " = 0u; int ma" << it.sfx << " = 0, sv" << it.sfx << " = -1, nd" << it.sfx << " = 0;\n";
+    // registers a thread keeps per item for the whole decode: channel dword, decided-bit dword, LDS dword index of the node's first
+    // edge (set * E + edge; negative: no item).  Set and node id are recomputed where they are needed (start and end only).
+    for (auto &it : items) o << "    uint32_t cha" << it.sfx << " = 0u, hard" << it.sfx << " = 0u; int ma" << it.sfx << " = -1;\n";
+    for (auto &it : items) {
+        const ResidentClass &C = R.vcls[(size_t)it.c];
+        o << "    auto sv" << it.sfx << " = [&]() { return (tid + " << it.r << " * NT - " << it.base << ") / " << C.n << "; };\n"
+          << "    auto nd" << it.sfx << " = [&]() { const int it = tid + " << it.r << " * NT - " << it.base << "; return A.idx[" << C.idx_off << " + it - (it / " << C.n << ") * " << C.n << "]; };\n";
+    }
     // init A: channel dwords, decided bits of the channel labels (src/LDPC_Code_LUT.cpp:275)
     for (auto &it : items) {
         const ResidentClass &C = R.vcls[(size_t)it.c];
-        o << "    {\n        const int it = tid + " << it.r << " * NT;\n        if (it < S * " << C.n << ") {\n"
+        o << "    {\n        const int it = tid + " << it.r << " * NT - " << it.base << ";\n        if (it >= 0 && it < S * " << C.n << ") {\n"
           << "            const int s = it / " << C.n << ", j = it - s * " << C.n << ", q = q0 + s;\n"
           << "            const int32_t *vt = A.idx + " << C.idx_off << ";\n"
-          << "            nd" << it.sfx << " = vt[2 * j]; ma" << it.sfx << " = s * E + vt[2 * j + 1]; sv" << it.sfx << " = s;\n"
-          << "            if (q < A.n_sets) cha" << it.sfx << " = *reinterpret_cast<const uint32_t *>(A.cha + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << ") * kRowBytes + (q & 63) * 4);\n"
+          << "            ma" << it.sfx << " = s * E + vt[" << C.n << " + j];\n"
+          << "            if (q < A.n_sets) cha" << it.sfx << " = *reinterpret_cast<const uint32_t *>(A.cha + ((size_t)(q >> 6) * N + (size_t)vt[j]) * kRowBytes + (q & 63) * 4);\n"
           << "            hard" << it.sfx << " = res_lt<PACK>(cha" << it.sfx << ", NZC);\n"
           << "        }\n    }\n";
     }
+    // check items: one sequence of slots over all check classes as well (widest checks first)
+    std::vector<int> cbase(NCC, 0);
+    std::vector<size_t> corder(NCC);
+    {
+        for (size_t c = 0; c < NCC; c++) corder[c] = c;
+        std::stable_sort(corder.begin(), corder.end(), [&](size_t a, size_t b) { return R.ccls[a].deg > R.ccls[b].deg; });
+        int base = 0;
+        for (size_t c : corder) { cbase[c] = base; base += S * R.ccls[c].n; }
+    }
+    // first item of class c this thread handles: slots tid, tid + NT, ... at or beyond the class base
+    auto cn_loop = [&](size_t c) {
+        const int b = cbase[c];
+        return "for (int it = tid + ((" + S_(b) + " - tid + NT - 1) / NT) * NT - " + S_(b) + "; it < S * " + S_(R.ccls[c].n) + "; it += NT) {\n";
+    };
     // ---- syndrome over the decided bits (src/LDPC_Code_LUT.cpp:455-469): bits exchanged through M[s * E + node]
     o << "    auto put_hard = [&]() {\n";
-    for (auto &it : items) o << "        if (sv" << it.sfx << " >= 0) M[sv" << it.sfx << " * E + nd" << it.sfx << "] = hard" << it.sfx << ";\n";
+    for (auto &it : items) o << "        if (ma" << it.sfx << " >= 0) M[sv" << it.sfx << "() * E + nd" << it.sfx << "()] = hard" << it.sfx << ";\n";
     o << "    };\n    auto syndrome = [&]() {\n";
-    for (size_t c = 0; c < NCC; c++) {
+    for (size_t c : corder) {
         const ResidentClass &C = R.ccls[c];
-        o << "        for (int it = tid; it < S * " << C.n << "; it += NT) {\n"
+        o << "        " << cn_loop(c)
           << "            const int s = it / " << C.n << ", j = it - s * " << C.n << ";\n"
           << "            const uint32_t a = L_act[s];\n            if (!a) continue;\n"
-          << "            const int32_t *nd = A.idx + " << C.nidx_off << " + (size_t)j * " << C.deg << ";\n"
-          << "            uint32_t acc = 0u;\n#pragma unroll 8\n            for (int k = 0; k < " << C.deg << "; k++) acc ^= M[s * E + nd[k]];\n"
+          << "            const int32_t *nd = A.idx + " << C.nidx_off << " + j;\n"
+          << "            uint32_t acc = 0u;\n#pragma unroll 8\n            for (int k = 0; k < " << C.deg << "; k++) acc ^= M[s * E + nd[k * " << C.n << "]];\n"
           << "            const uint32_t f = acc & a;\n            if (f) atomicOr(&L_fail[s], f);\n        }\n";
     }
     o << "    };\n";
@@ -300,8 +335,8 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     o << "    if (alive) {\n";
     for (auto &it : items) {
         const ResidentClass &C = R.vcls[(size_t)it.c];
-        o << "        if (sv" << it.sfx << " >= 0) {\n            const int q = q0 + sv" << it.sfx << ";\n"
-          << "            const uint32_t m0 = q < A.n_sets ? *reinterpret_cast<const uint32_t *>(A.msg0 + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << ") * kRowBytes + (q & 63) * 4) : 0u;\n"
+        o << "        if (ma" << it.sfx << " >= 0) {\n            const int q = q0 + sv" << it.sfx << "();\n"
+          << "            const uint32_t m0 = q < A.n_sets ? *reinterpret_cast<const uint32_t *>(A.msg0 + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4) : 0u;\n"
           << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) M[ma" << it.sfx << " + k] = m0;\n        }\n";
     }
     if (!R.min_lut) o << "        stage_chk(kSet[0]);\n";
@@ -311,16 +346,16 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     o << "    auto cn_pass = [&](int ii, bool chk) {\n        const uint32_t nz = (uint32_t)kNz[ii];\n        (void)nz;\n";
     if (R.min_lut) {
         o << "        const int sbit = __builtin_ctz(nz);\n        const uint32_t SB = nz * ONE, LOW = SB - ONE;\n";
-        for (size_t c = 0; c < NCC; c++) {
+        for (size_t c : corder) {
             const ResidentClass &C = R.ccls[c];
             if (C.deg < 2) { err = "check of degree 1"; return false; }
-            o << "        for (int it = tid; it < S * " << C.n << "; it += NT) {\n"
+            o << "        " << cn_loop(c)
               << "            const int s = it / " << C.n << ", j = it - s * " << C.n << ";\n"
               << "            const uint32_t a = L_act[s];\n            if (!a) continue;\n            const uint32_t am = res_mask<PACK>(a);\n"
-              << "            const int32_t *ed = A.idx + " << C.idx_off << " + (size_t)j * " << C.deg << ";\n            uint32_t *Ms = M + s * E;\n";
+              << "            const int32_t *ed = A.idx + " << C.idx_off << " + j;\n            uint32_t *Ms = M + s * E;\n            constexpr int ES = " << C.n << ";      // [k][node] table: entry k of this check at ed[k * ES]\n";
             if (C.deg <= 16) {
                 o << "            int e[" << C.deg << "]; uint32_t x[" << C.deg << "], r[" << C.deg << "];\n"
-                  << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) e[k] = ed[k];\n"
+                  << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) e[k] = ed[k * ES];\n"
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) x[k] = Ms[e[k]];\n"
                   << "            const uint32_t tn = res_minsum<" << C.deg << ", PACK>(x, r, sbit, SB, LOW);\n"
                   << "            if (chk) { const uint32_t f = (tn >> sbit) & a; if (f) atomicOr(&L_fail[s], f); }\n"
@@ -328,7 +363,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
             } else {
                 // wide checks: two sweeps over the check's edges (the messages are re-read from LDS instead of held in registers)
                 o << "            uint32_t min1 = LOW, min2 = LOW, spp = 0u;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                const uint32_t xh = Ms[ed[k]];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
+                  << "                const uint32_t xh = Ms[ed[k * ES]];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
                   << "                spp ^= xh;\n                const uint32_t g1 = ((mag | SB) - min1) & SB, k1 = g1 - (g1 >> sbit);\n"
                   << "                const uint32_t lo = bfi(k1, min1, mag), hi = mag ^ min1 ^ lo;\n"
                   << "                const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
@@ -336,7 +371,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "            const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
                   << "            if (chk) { const uint32_t f = (tn >> sbit) & a; if (f) atomicOr(&L_fail[s], f); }\n"
                   << "            const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                const int ek = ed[k];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
+                  << "                const int ek = ed[k * ES];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
                   << "                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
                   << "                const uint32_t mc = bfi(ke, m2c, m1c), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
                   << "                Ms[ek] = bfi(am, (mc ^ kp) | po, xh);\n            }\n";
@@ -346,7 +381,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     } else {
         // CHKTREE check update: one code variant per distinct program text, selected by the tree set of the iteration
         o << "        const int set = kSet[ii];\n";
-        for (size_t c = 0; c < NCC; c++) {
+        for (size_t c : corder) {
             const ResidentClass &C = R.ccls[c];
             std::vector<std::string> bodies;
             std::vector<int> variant_of(n_sets_tree, -1);
@@ -360,13 +395,13 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                 variant_of[s] = (int)v;
             }
             emit_int_array(o, "kChkVar" + S_((long long)c), variant_of);
-            o << "        for (int it = tid; it < S * " << C.n << "; it += NT) {\n"
+            o << "        " << cn_loop(c)
               << "            const int s = it / " << C.n << ", j = it - s * " << C.n << ";\n"
               << "            const uint32_t a = L_act[s];\n            if (!a) continue;\n            const uint32_t am = res_mask<PACK>(a);\n"
-              << "            const int32_t *ed = A.idx + " << C.idx_off << " + (size_t)j * " << C.deg << ";\n            uint32_t *Ms = M + s * E;\n"
+              << "            const int32_t *ed = A.idx + " << C.idx_off << " + j;\n            uint32_t *Ms = M + s * E;\n            constexpr int ES = " << C.n << ";\n"
               << "            const uint8_t *tc = TC + " << tc_off[c] << ";\n"
               << "            int e[" << C.deg << "]; uint32_t x[" << C.deg << "], out[" << C.deg << "];\n            uint32_t par_w = 0u;\n"
-              << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) { e[k] = ed[k]; out[k] = 0u; }\n"
+              << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) { e[k] = ed[k * ES]; out[k] = 0u; }\n"
               << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) x[k] = Ms[e[k]];\n"
               << "            switch (kChkVar" << c << "[set]) {\n";
             for (size_t v = 0; v < bodies.size(); v++) o << "            case " << v << ": {\n" << bodies[v] << "            } break;\n";
@@ -389,7 +424,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
         std::vector<std::vector<std::string>> bodies(NVC);
         std::vector<std::vector<int>> variant_of(NVC, std::vector<int>(n_sets_tree, -1));
         for (size_t c = 0; c < NVC; c++) {
-            const int deg = R.vcls[c].deg, U = deg <= 8 ? 2 : 1;
+            const int deg = R.vcls[c].deg, U = R.U > 0 ? R.U : (deg <= 8 ? 2 : 1);
             for (size_t s = 0; s < n_sets_tree; s++) {
                 if (s >= progs.size() || c >= progs[s].size() || !progs[s][c]) continue;
                 std::ostringstream b;
@@ -404,7 +439,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
         for (auto &it : items) {
             const ResidentClass &C = R.vcls[(size_t)it.c];
             const int deg = C.deg;
-            o << "        if (sv" << it.sfx << " >= 0) {\n            const uint32_t a = L_act[sv" << it.sfx << "];\n            if (a) {\n"
+            o << "        if (ma" << it.sfx << " >= 0) {\n            const int sv = sv" << it.sfx << "();\n            const uint32_t a = L_act[sv];\n            if (a) {\n"
               << "                const uint32_t am = res_mask<PACK>(a);\n                const uint8_t *tb = TV + " << tv_off[(size_t)it.c] << ";\n"
               << "                uint32_t raw[" << deg + 1 << "], out[" << deg << "], hardw = 0u;\n"
               << "#pragma unroll\n                for (int k = 0; k < " << deg << "; k++) { raw[k] = M[ma" << it.sfx << " + k]; out[k] = 0u; }\n"
@@ -424,7 +459,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                     o << "                    hardw = res_lt<PACK>(out[0], nzo);\n#pragma unroll\n                    for (int k = 1; k < " << deg << "; k++) diff |= res_lt<PACK>(out[k], nzo) ^ hardw;\n"
                       << "                    const uint32_t f = diff & a;\n";
                 }
-                o << "                    if (f) atomicOr(&L_fail[sv" << it.sfx << "], f);\n"
+                o << "                    if (f) atomicOr(&L_fail[sv], f);\n"
                   << "                    hard" << it.sfx << " = bfi(am, hardw, hard" << it.sfx << ");\n                }\n"
                   << "#pragma unroll\n                for (int k = 0; k < " << deg << "; k++) M[ma" << it.sfx << " + k] = bfi(am, out[k], raw[k]);\n";
             }
@@ -451,8 +486,8 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
       << "#pragma unroll\n            for (int n = 0; n < F; n++)\n                if ((a >> (n * BITS)) & 1u) A.iters[f0 + res_frame_of_element<PACK>(n)] = ((f >> (n * BITS)) & 1u) ? -max_iters : max_iters;\n        }\n    }\n";
     // ---- decided bits back to their rows
     for (auto &it : items)
-        o << "    if (sv" << it.sfx << " >= 0 && q0 + sv" << it.sfx << " < A.n_sets) { const int q = q0 + sv" << it.sfx
-          << "; *reinterpret_cast<uint32_t *>(A.hard + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << ") * kRowBytes + (q & 63) * 4) = hard" << it.sfx << "; }\n";
+        o << "    if (ma" << it.sfx << " >= 0 && q0 + sv" << it.sfx << "() < A.n_sets) { const int q = q0 + sv" << it.sfx
+          << "(); *reinterpret_cast<uint32_t *>(A.hard + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4) = hard" << it.sfx << "; }\n";
     o << "}\n";
     src = o.str();
     return true;

@@ -30,6 +30,9 @@ struct TreeNode {
     int type = 0;
     int K = 0;                     // output alphabet
     std::vector<int> Q;            // half table as stored by the reference
+    // composed nodes (compose_tree below) carry their FULL table in the look-up's own indexing: VAR / DEC: index = sum of child
+    // label * place value; CHK: [odd-parity half | even-parity half], each indexed by the children's magnitudes
+    std::vector<uint8_t> full;
     std::vector<std::unique_ptr<TreeNode>> child;
     bool is_leaf() const { return type == NT_MSG || type == NT_CHA; }
 };
@@ -102,6 +105,7 @@ inline bool parse_tree_array(const char *txt, TreeArray &out, std::string &err) 
 
 // ---- compiled node program -----------------------------------------------------------------
 constexpr int kMaxChildren = 8;
+constexpr int kMaxChildrenCompose = 4;      // fan-in of a composed node (compose_tree)
 
 struct Op {                 // one LUT look-up
     uint32_t tab_off;       // byte offset of its full table inside the class blob
@@ -185,6 +189,14 @@ inline bool expand_table(const TreeNode *n, int kind, std::vector<uint8_t> &blob
     if (n->K < 2 || n->K > 256) { err = "node output alphabet must be in [2,256]"; return false; }
     size_t L = n->Q.size();
     off = (uint32_t)blob.size();
+    if (!n->full.empty()) {        // composed node: the table is there already
+        const uint64_t want = kind == TT_CHK ? 2 * space : space;
+        if (n->full.size() != want) { err = "composed table length does not match its inputs"; return false; }
+        len = (uint32_t)want; half = kind == TT_CHK ? (uint32_t)space : 0u;
+        blob.insert(blob.end(), n->full.begin(), n->full.end());
+        while (blob.size() & 3) blob.push_back(0);
+        return true;
+    }
     if (kind == TT_CHK) {
         // src/LUT_Tree.cpp:441-444: odd sign parity -> Q[label], even -> K-1-Q[label]
         if (L != space) { err = "check LUT length does not match its inputs"; return false; }
@@ -203,6 +215,123 @@ inline bool expand_table(const TreeNode *n, int kind, std::vector<uint8_t> &blob
 }
 
 }  // namespace detail
+
+// ---- exact table composition ---------------------------------------------------------------------------------------
+// A LUT node X whose value feeds ONE input of its parent P can be folded into P: P'(..., children of X, ...) with the table
+// T'[...] = T_P[..., T_X[...], ...] gives the same output for every input tuple (the maps Q are plain functions of the labels,
+// src/LUT_Tree.cpp:402-418 / 420-445), so the decoder stays bit-exact while X's look-ups disappear -- for the balanced trees of
+// a degree-8 node 34 look-ups per frame become 20, for degree 3 six become three.  The leaves of X take X's place in P's child
+// list, so the depth-first leaf order (= the order in which the queue is consumed) does not change.
+// CHK nodes work on (sign, magnitude): the composed output depends on the signs only through their total parity (the sign of
+// X's output is parity_X xor a function of the magnitudes), so P' is again a [odd | even] pair of magnitude-indexed tables.
+// Greedy, bottom-up: a node absorbs internal children while the label space stays <= max_space and the fan-in <= 8.
+namespace detail {
+
+inline uint64_t node_space(const TreeNode *n, int kind) {
+    uint64_t sp = 1;
+    for (auto &c : n->child) sp *= (uint64_t)(kind == TT_CHK ? c->K / 2 : c->K);
+    return sp;
+}
+inline bool node_is_leaf(const TreeNode *n, int kind) { return kind == TT_CHK ? n->type == NT_MSG : n->is_leaf(); }
+
+// full table of a node in the look-up's indexing (see TreeNode::full)
+inline bool node_full_table(const TreeNode *n, int kind, std::vector<uint8_t> &t) {
+    if (!n->full.empty()) { t = n->full; return true; }
+    std::vector<uint8_t> blob;
+    uint32_t off, len, half;
+    std::string err;
+    if (!expand_table(n, kind, blob, off, len, half, err)) return false;
+    t.assign(blob.begin(), blob.begin() + len);
+    return true;
+}
+
+// fold child number `ci` of P into P
+inline bool absorb_child(TreeNode *P, size_t ci, int kind) {
+    TreeNode *X = P->child[ci].get();
+    std::vector<uint8_t> TP, TX;
+    if (!node_full_table(P, kind, TP) || !node_full_table(X, kind, TX)) return false;
+    const size_t nP = P->child.size(), nX = X->child.size(), nN = nP - 1 + nX;
+    auto alph = [&](const TreeNode *c) { return (uint64_t)(kind == TT_CHK ? c->K / 2 : c->K); };
+    std::vector<uint64_t> aP, aX, aN;
+    for (auto &c : P->child) aP.push_back(alph(c.get()));
+    for (auto &c : X->child) aX.push_back(alph(c.get()));
+    for (size_t i = 0; i < nP; i++) { if (i == ci) aN.insert(aN.end(), aX.begin(), aX.end()); else aN.push_back(aP[i]); }
+    uint64_t spN = 1, spP = 1, spX = 1;
+    for (auto a : aN) spN *= a;
+    for (auto a : aP) spP *= a;
+    for (auto a : aX) spX *= a;
+    const int hX = X->K / 2;
+    std::vector<uint8_t> TN((size_t)(kind == TT_CHK ? 2 * spN : spN));
+    std::vector<uint64_t> dig(nN);
+    for (uint64_t idx = 0; idx < spN; idx++) {
+        uint64_t r = idx;
+        for (size_t i = 0; i < nN; i++) { dig[i] = r % aN[i]; r /= aN[i]; }           // child 0 least significant
+        uint64_t labX = 0, mul = 1;
+        for (size_t i = 0; i < nX; i++) { labX += mul * dig[ci + i]; mul *= aX[i]; }
+        if (kind != TT_CHK) {
+            const uint64_t xo = TX[(size_t)labX];
+            uint64_t labP = 0; mul = 1;
+            for (size_t i = 0, j = 0; i < nP; i++) { const uint64_t v = (i == ci) ? xo : dig[j]; labP += mul * v; mul *= aP[i]; j += (i == ci) ? nX : 1; }
+            TN[(size_t)idx] = TP[(size_t)labP];
+        } else {
+            for (int par_all = 0; par_all < 2; par_all++) {          // 1 = odd number of negative leaves; put that sign on X's first leaf
+                const uint64_t xo = TX[(size_t)(par_all ? labX : spX + labX)];
+                const bool negx = (int)xo < hX;
+                const uint64_t magx = negx ? (uint64_t)(hX - 1) - xo : xo - (uint64_t)hX;
+                uint64_t labP = 0; mul = 1;
+                for (size_t i = 0, j = 0; i < nP; i++) { const uint64_t v = (i == ci) ? magx : dig[j]; labP += mul * v; mul *= aP[i]; j += (i == ci) ? nX : 1; }
+                const uint8_t out = TP[(size_t)(negx ? labP : spP + labP)];    // P's parity = sign of X's output (all other inputs positive)
+                TN[(size_t)(par_all ? idx : spN + idx)] = out;
+            }
+        }
+    }
+    std::vector<std::unique_ptr<TreeNode>> nc;
+    for (size_t i = 0; i < nP; i++) {
+        if (i == ci) for (auto &xc : X->child) nc.push_back(std::move(xc));
+        else nc.push_back(std::move(P->child[i]));
+    }
+    P->child = std::move(nc);
+    P->full = std::move(TN);
+    P->Q.clear();
+    return true;
+}
+
+inline void compose_node(TreeNode *P, int kind, uint64_t max_space) {
+    if (node_is_leaf(P, kind)) return;
+    for (auto &c : P->child) compose_node(c.get(), kind, max_space);
+    for (;;) {
+        // the internal child whose absorption gives the smallest label space
+        size_t best = (size_t)-1; uint64_t best_sp = 0;
+        const uint64_t sp = node_space(P, kind);
+        for (size_t i = 0; i < P->child.size(); i++) {
+            const TreeNode *X = P->child[i].get();
+            if (node_is_leaf(X, kind) || X->child.empty()) continue;
+            const uint64_t a = (uint64_t)(kind == TT_CHK ? X->K / 2 : X->K);
+            const uint64_t nsp = sp / a * node_space(X, kind);
+            if (nsp > max_space || P->child.size() - 1 + X->child.size() > (size_t)kMaxChildrenCompose) continue;
+            if (best == (size_t)-1 || nsp < best_sp) { best = i; best_sp = nsp; }
+        }
+        if (best == (size_t)-1 || !absorb_child(P, best, kind)) return;
+    }
+}
+
+inline std::unique_ptr<TreeNode> clone_node(const TreeNode *n) {
+    std::unique_ptr<TreeNode> c(new TreeNode);
+    c->type = n->type; c->K = n->K; c->Q = n->Q; c->full = n->full;
+    for (auto &ch : n->child) c->child.push_back(clone_node(ch.get()));
+    return c;
+}
+
+}  // namespace detail
+
+// a composed copy of the tree (max_space: largest label space of a composed node; the tables are bytes: <= 4096 keeps a class
+// of degree 8 within 13 KB of LDS)
+inline Tree compose_tree(const Tree &t, int kind, uint64_t max_space) {
+    Tree c;
+    c.type = t.type; c.num_leaves = t.num_leaves;
+    if (t.root) { c.root = detail::clone_node(t.root.get()); detail::compose_node(c.root.get(), kind, max_space); }
+    return c;
+}
 
 // Compile the tree for a node of degree d.  VAR: inputs = d messages + channel label, d
 // outputs (output i walks the queue with element i removed, src/LUT_Tree.cpp:783-788);

@@ -117,6 +117,16 @@ class Decoder:
         lib.lutldpc_selftest_jit_source(self._h, kind, tree_set, cls, buf, n, 0)
         return buf.value.decode()
 
+    def resident_source(self, G: int, compile: bool = False):
+        """HIP source of the LDS-resident decode kernel for G frame groups, and (sets per workgroup, threads, LDS bytes)."""
+        info = (C.c_int32 * 3)()
+        n = lib.lutldpc_selftest_resident_source(self._h, int(G), None, 0, int(compile), info)
+        if n < 0:
+            check(int(n))
+        buf = C.create_string_buffer(n)
+        lib.lutldpc_selftest_resident_source(self._h, int(G), buf, n, 0, info)
+        return buf.value.decode(), tuple(info)
+
     # ---- compile-step self test (host only) ----------------------------------------------------
     def program_eval(self, kind: int, tree_set: int, cls: int, inputs, n_out: int):
         a = _i32(inputs)

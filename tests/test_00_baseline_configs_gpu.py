@@ -40,7 +40,9 @@ def test_c3_c2_full_iteration_count_default_path(name, snr, n_oracle):
     desc = dec.describe()
     assert desc["pack"] == 2 and desc["skewed_pipeline"] == 1 and desc["use_fast"] == 1, desc
     if name == "dvbs2_q4":
-        assert desc["fused_bucket"] == 0 and desc["chain_nodes"] == 29699, desc
+        assert desc["fused_bucket"] == 0 and desc["chain_nodes"] == 29699 and desc["resident"] == 0, desc
+    else:
+        assert desc["resident"] == 1, desc                      # (3,6) N=10000: 120 KB of edge messages per 8 frames -> decoded out of LDS
     B = 1100
     cha, msg, _ = awgn_labels(cd, B, snr, seed=2026)
     for psc in (True, False):
@@ -115,7 +117,7 @@ def test_c5_wide_checks(name):
     (as shipped) and the 31-leaf CHKTREE (min_lut = false).  700 frames = two frame groups, generated kernels."""
     cd = oracle_codec(name)
     dec = product_decoder(cd)
-    assert dec.describe()["vn_classes"][0]["kernel"] == "lutldpc_jit_pass", dec.describe()
+    assert dec.describe()["vn_classes"][0]["kernel"] == "lutldpc_jit_pass" and dec.describe()["resident"] == 1, dec.describe()
     cha, msg, _ = awgn_labels(cd, 700, 4.0, seed=31, mode=1)
     compare(cd, dec, cha, msg, True, True)
     compare(cd, dec, cha, msg, False, False)

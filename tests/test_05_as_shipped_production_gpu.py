@@ -35,6 +35,7 @@ def test_ira_code_chain_fusion_with_compaction(tmp_path, monkeypatch, K, M, dv, 
     (halves of 5 + 4 / 5 + 5, ragged last group), both row flows (the frames that left keep their rows / drop them), all three
     exit modes, EVERY frame against the oracle.  Some frames are noise-free: they pass the test on the channel decisions and are
     moved by the first permutation like every other finished frame."""
+    monkeypatch.setenv("LUTLDPC_RESIDENT", "0")              # the streaming path: this small code would otherwise be decoded out of LDS
     monkeypatch.setenv("LUTLDPC_COMPACT", "1")
     monkeypatch.setenv("LUTLDPC_COMPACT_KEEP", keep)
     monkeypatch.setenv("LUTLDPC_COMPACT_FIRST", "2")
@@ -138,11 +139,13 @@ def test_dvbs2_as_shipped_equals_the_path_without_compaction(monkeypatch):
 
 
 @pytest.mark.parametrize("nq_cha", [12, 6])
-def test_channel_alphabet_whose_half_is_not_a_power_of_two(nq_cha):
+@pytest.mark.parametrize("resident", ["0", "1"])
+def test_channel_alphabet_whose_half_is_not_a_power_of_two(nq_cha, resident, monkeypatch):
     """Nq_Cha = 12 / 6: `label < Nq_Cha/2` (src/LDPC_Code_LUT.cpp:275) is not a sign BIT of the label; the test on the channel
     decisions (pisc) must go through the SWAR compare, not the bit trick of the label-row syndrome kernel."""
     from helpers import CODES
     from oracle import oracle as orc
+    monkeypatch.setenv("LUTLDPC_RESIDENT", resident)
     code = orc.Code(CODES / "rate0.50_dv03_dc06_N1000.alist")
     cd = orc.Codec(code, skip_rank=True)
     cd.set_rank(500)

@@ -24,9 +24,14 @@ CASES = [
 
 @pytest.mark.parametrize("name,B,snr", CASES)
 @pytest.mark.parametrize("psc,pisc", [(False, False), (True, False), (True, True)])
-def test_lut_decode_matches_oracle(name, B, snr, psc, pisc):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_lut_decode_matches_oracle(name, B, snr, psc, pisc, resident, monkeypatch):
+    """resident = 1: the default for these codes -- one generated kernel keeps the messages in LDS for the whole decode
+    (jit_resident.hpp); resident = 0: the streaming kernels (rows in HBM, one launch per pass)."""
+    monkeypatch.setenv("LUTLDPC_RESIDENT", resident)
     cd = oracle_codec(name)
     dec = product_decoder(cd)
+    assert dec.describe()["resident"] == (int(resident) if name != "c5_chklut" else 0)      # (wide CHKTREE checks: streaming kernels)
     mode = 1 if name.startswith("c5") else 0
     cha, msg, _ = awgn_labels(cd, B, snr, seed=100 + B, mode=mode)
     # frame 0: noise-free all-zero codeword (pisc returns 0), frame 1: all labels identical minimum
@@ -40,12 +45,10 @@ def test_lut_decode_matches_oracle(name, B, snr, psc, pisc):
 
 
 @pytest.mark.parametrize("name,B,snr", [("n500_q4", 1100, 1.6), ("reg36_n1000_q4", 1537, 2.0), ("reg36_n1000_mixed", 1025, 2.2), ("dvbs2_q4_i6", 1030, 1.0)])
-@pytest.mark.parametrize("env", [{}])
+@pytest.mark.parametrize("env", [{"LUTLDPC_RESIDENT": "0"}])
 def test_skewed_pipeline(name, B, snr, env, monkeypatch):
     """Batches of two or more frame groups run as two halves half an iteration out of phase
     (pass_fused_kernel): uneven halves, ragged last group, early termination on and off."""
-    if name.startswith("dvbs2") and env:
-        pytest.skip("large code: default configuration only")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cd = oracle_codec(name)
@@ -63,6 +66,7 @@ def test_skewed_pipeline(name, B, snr, env, monkeypatch):
 @pytest.mark.parametrize("name", ["c5_minlut", "reg36_n1000_rootonly", "reg36_n1000_high", "reg36_n1000_q5", "c5_chklut", "reg36_n1000_q3_chklut"])
 def test_generated_kernels_are_used_and_match(name, monkeypatch):
     """jit.hpp: the kernel generated from the node program vs the oracle, and vs the interpreter (LUTLDPC_JIT=0)."""
+    monkeypatch.setenv("LUTLDPC_RESIDENT", "0")           # the per-class pass kernels of the streaming path are what is tested here
     cd = oracle_codec(name)
     dec = product_decoder(cd)
     # (degree 3: auto_bin_high over two message leaves IS the balanced shape -> compile-time kernel)
@@ -101,10 +105,12 @@ def test_chain_fusion_is_on_for_the_dual_diagonal_code():
     dec.close()
 
 
-def test_graph_replay_of_repeated_decodes():
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_graph_replay_of_repeated_decodes(resident, monkeypatch):
     """From the second decode of a given (batch size, exit conditions) on, the launch sequence is captured
     and replayed as one hipGraph: new labels in the same buffers, changed exit conditions, a batch size
     that forces bigger buffers (captured addresses become stale) and a return to the first size."""
+    monkeypatch.setenv("LUTLDPC_RESIDENT", resident)
     cd = oracle_codec("reg36_n1000_q4")
     dec = product_decoder(cd)
     for rep, (B, psc, pisc) in enumerate([(600, True, True), (600, True, True), (600, True, True), (600, False, False), (600, False, False),
@@ -116,7 +122,9 @@ def test_graph_replay_of_repeated_decodes():
 
 
 @pytest.mark.parametrize("B", [1, 3, 255, 256, 257, 511, 512, 513])
-def test_batch_sizes(B):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_batch_sizes(B, resident, monkeypatch):
+    monkeypatch.setenv("LUTLDPC_RESIDENT", resident)
     cd = oracle_codec("n500_q4_i8")
     dec = product_decoder(cd)
     cha, msg, _ = awgn_labels(cd, B, 2.0, seed=B)
@@ -152,11 +160,13 @@ def test_fewer_iterations_than_designed_is_rejected_unless_decision_set():
 
 
 @pytest.mark.parametrize("K,M,dv,bucket", [(1600, 400, 3, 1), (3600, 400, 3, 2), (840, 420, 3, 0), (1120, 420, 3, 3)])
-def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket):
-    """Dual-diagonal codes with check degrees 14 (middle bucket), 29 (widest), 8 (first) and 10 (bucket 3): most zigzag nodes are updated
+def test_chain_fusion_in_every_degree_bucket(tmp_path, K, M, dv, bucket, monkeypatch):
+    """(streaming kernels: LUTLDPC_RESIDENT=0 -- these small codes would otherwise be decoded out of LDS)
+    Dual-diagonal codes with check degrees 14 (middle bucket), 29 (widest), 8 (first) and 10 (bucket 3): most zigzag nodes are updated
     inside the check pass in every bucket, one frame group and several, fixed work and early termination."""
     from helpers import write_ira_alist
     from oracle import oracle as orc
+    monkeypatch.setenv("LUTLDPC_RESIDENT", "0")
     N, _ = write_ira_alist(tmp_path / "ira.alist", K, M, dv, seed=K)
     code = orc.Code(tmp_path / "ira.alist")
     cd = orc.Codec(code, skip_rank=True)
@@ -215,12 +225,14 @@ FUZZ = [  # N, M, variable degrees, their shares, Nq_Cha, Nq_Msg, iterations, de
 
 
 @pytest.mark.parametrize("case", range(len(FUZZ)))
-def test_random_irregular_codes(tmp_path, case):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_random_irregular_codes(tmp_path, case, resident, monkeypatch):
     """Random irregular graphs the build has never seen (several variable and check degree classes, check degrees that differ
     by one, wide and narrow checks, 3- and 4-bit alphabets): design with the oracle, decode through the default path, every
     bit and iteration code against the oracle in all three exit modes, ragged batch sizes."""
     from helpers import write_random_alist
     from oracle import oracle as orc
+    monkeypatch.setenv("LUTLDPC_RESIDENT", resident)
     N, M, dvc, dvp, nqc, nqm, I, sig, B = FUZZ[case]
     dv, dc = write_random_alist(tmp_path / "r.alist", N, M, dvc, dvp, seed=100 + case)
     code = orc.Code(tmp_path / "r.alist")

@@ -105,3 +105,76 @@ def _has_dec(dec, s):
         return True
     except Exception:
         return False
+
+
+COMPOSED = 16      # kind + 16: the program of the same tree after exact table composition (lut_program.hpp: compose_tree)
+
+
+@pytest.mark.parametrize("name", ["n500_q4_i8", "reg36_n1000_mixed", "reg36_n1000_q3_chklut", "reg36_n1000_rootonly", "reg36_n1000_high",
+                                  "c5_chklut", "dvbs2_q4_i6"])
+def test_composed_programs_match_oracle_tree_walk(name):
+    """Table composition folds a LUT node into its parent (T'[...] = T_P[..., T_X[...], ...]): fewer look-ups, the same function.
+    Every composed program against the oracle's queue / recursion walk of the ORIGINAL tree on random inputs."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)
+    rng = np.random.default_rng(12)
+    degs_v = sorted(set(cd.code.dv.tolist()))
+    degs_c = sorted(set(cd.code.dc.tolist()))
+    n_sets = cd.n_sets()
+    set_iters = np.flatnonzero(np.asarray(cd.reuse_vec) == 0)
+    fewer = 0
+    for s in range(n_sets):
+        k_in = int(cd.nq_msg[int(set_iters[s])])
+        kind = DEC if s == n_sets - 1 else VAR
+        for cls, dv in enumerate(degs_v):
+            _check_composed(cd, dec, kind, s, cls, dv, 60, rng, k_in, cd.nq_cha)
+            fewer += dec.program_stats(kind, s, cls)["ops"] - dec.program_stats(kind + COMPOSED, s, cls)["ops"]
+        if not cd.min_lut:
+            for cls, dc in enumerate(degs_c):
+                _check_composed(cd, dec, CHK, s, cls, dc, 40, rng, k_in, cd.nq_cha)
+                fewer += dec.program_stats(CHK, s, cls)["ops"] - dec.program_stats(CHK + COMPOSED, s, cls)["ops"]
+    assert fewer > 0 or name == "reg36_n1000_rootonly"          # (root_only: one 3-input table already, nothing to fold)
+    dec.close()
+
+
+def _check_composed(cd, dec, kind, tree_set, cls, deg, n_trials, rng, k_in, k_cha):
+    n_in = deg if kind == CHK else deg + 1
+    n_out = 1 if kind == DEC else deg
+    for _ in range(n_trials):
+        x = rng.integers(0, k_in, n_in).astype(np.int32)
+        if kind != CHK:
+            x[-1] = rng.integers(0, k_cha)
+        want = cd.tree_eval(kind, tree_set, cls, x, n_out)
+        got = dec.program_eval(kind + COMPOSED, tree_set, cls, x, n_out)
+        assert (want == got).all(), (kind, tree_set, cls, x, want, got)
+
+
+def test_composition_look_up_counts():
+    """Balanced trees: degree 3 -> three 3-input look-ups instead of six; degree 8 -> 20 instead of 34."""
+    cd = oracle_codec("dvbs2_q4_i6")
+    dec = product_decoder(cd, device=-1)
+    degs = sorted(set(cd.code.dv.tolist()))
+    ops = {dv: (dec.program_stats(VAR, 0, c)["ops"], dec.program_stats(VAR + COMPOSED, 0, c)["ops"]) for c, dv in enumerate(degs)}
+    assert ops[3] == (6, 3) and ops[8] == (34, 20) and ops[2] == (2, 2), ops
+    dec.close()
+
+
+@pytest.mark.parametrize("name,G", [("n500_q4_i8", 3), ("reg36_n1000_mixed", 1), ("c5_chklut", 2), ("c5_minlut", 64), ("reg36_n10000_q4", 8), ("reg36_n1000_q5", 2)])
+def test_resident_source_compiles_without_a_gpu(name, G):
+    """The LDS-resident decode kernel (jit_resident.hpp) is generated per code and batch shape; hiprtc cross-compiles it here."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)
+    src, (S, NT, lds) = dec.resident_source(G, compile=True)
+    assert "lutldpc_jit_pass" in src and "__shared__" in src and S >= 1 and NT in (256, 512, 1024) and lds <= 160 * 1024 - 2048
+    assert S * cd.code.nedges * 4 <= lds
+    dec.close()
+
+
+def test_resident_refuses_codes_that_do_not_fit_the_lds():
+    import lut_ldpc_amd as L
+    cd = oracle_codec("dvbs2_q4_i6")
+    dec = product_decoder(cd, device=-1)
+    assert dec.describe()["resident"] == 0
+    with pytest.raises(L.LutLdpcError):
+        dec.resident_source(4)
+    dec.close()

@@ -11,13 +11,21 @@ from helpers import awgn_labels, compare as _compare, oracle_codec, product_deco
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [{}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"},
+@pytest.fixture(autouse=True)
+def _streaming_kernels(monkeypatch):
+    """Everything in this file is about the STREAMING kernels (rows in HBM): the codes that would otherwise be decoded out of LDS
+    by the generated resident kernel (the default for N <= ~35000 edges) are pinned to them; the resident path is one of PATHS."""
+    monkeypatch.setenv("LUTLDPC_RESIDENT", "0")
+
+
+PATHS = [{}, {"LUTLDPC_RESIDENT": "1"}, {"LUTLDPC_SKEW": "0"}, {"LUTLDPC_PACK": "1"}, {"LUTLDPC_USE_FAST": "0"}, {"LUTLDPC_GRAPH": "0", "LUTLDPC_VN_EDGES_PER_WAVE": "8"},
          {"LUTLDPC_CHAIN": "0"}, {"LUTLDPC_CN_EDGES_PER_WAVE": "56", "LUTLDPC_PACK": "1"}]
 
 
 def _decode(cd, cha, msg, psc, env, monkeypatch, repeat=1):
     for k in ("LUTLDPC_SKEW", "LUTLDPC_PACK", "LUTLDPC_USE_FAST", "LUTLDPC_GRAPH", "LUTLDPC_VN_EDGES_PER_WAVE", "LUTLDPC_CHAIN", "LUTLDPC_CN_EDGES_PER_WAVE"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LUTLDPC_RESIDENT", "0")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     dec = product_decoder(cd)

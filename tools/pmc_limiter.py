@@ -5,7 +5,7 @@ per launch of pass_fused_kernel the share of the launch during which the vector 
 rocprofv3 sums every counter over the 8 XCDs of an MI355X; GRBM_GUI_ACTIVE is therefore 8 x the cycles of the launch.
     valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * launch cycles)       (rocprof's VALUBusy)
     lds_busy  = SQ_LDS_IDX_ACTIVE / (256 CUs * launch cycles)                (bank-conflict cycles included)
-Usage: tools/pmc_limiter.py <dir> <out.json> [kernel substring]"""
+Usage: tools/pmc_limiter.py <dir> <out.json> [kernel substring] [workload name]"""
 import collections, csv, json, pathlib, re, sys
 
 src, out = pathlib.Path(sys.argv[1]), pathlib.Path(sys.argv[2])
@@ -35,6 +35,7 @@ res = {
 bench = src / "bench.json"
 if bench.exists():
     b = json.loads(bench.read_text().strip().splitlines()[-1])
-    res.update({"workload": "dvbs2", "batch": b["config"]["frames_per_gpu_per_step"], "mode": "fixed"})
+    res.update({"workload": (sys.argv[4] if len(sys.argv) > 4 else "dvbs2"), "batch": b["config"]["frames_per_gpu_per_step"], "mode": "fixed",
+                "build": b["config"]["kernels"].get("build")})
 out.write_text(json.dumps(res, indent=1))
 print(json.dumps({k: v for k, v in res.items() if k != "counters_per_launch"}, indent=1))

@@ -4,18 +4,19 @@
 #   <out>/kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command
 #   <out>/pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv   HBM traffic, separate --pmc passes (kernel trace only)
 #   <out>/pmc_sq_a.csv, pmc_sq_b.csv what limits the fused kernel on the chip (VALU issue, LDS, waits)
-# Usage: tools/profile_round.sh <out-dir> [extra bench args]
+# Usage: [BENCH_ARGS="--workload c2 --batch 4096"] tools/profile_round.sh <out-dir> [the same extra bench args]
+# (BENCH_ARGS reaches the counter passes, "$@" the bench line and the kernel trace: give both for another workload)
 set -e
 OUT=$1; shift
 mkdir -p "$OUT"
 R=$GRAFT_REPO_ROOT
 python3 "$R/bench.py" "$@" > "$R/$OUT/bench.json" 2> "$R/$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline --frame-loop-steps 0 --as-shipped-steps 0 --reps 0 "$@" > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/trace" -- python3 "$R/bench.py" --no-cpu-baseline --no-configs --frame-loop-steps 0 --as-shipped-steps 0 --reps 0 "$@" > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/trace.err"
 find "$R/$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$R/$OUT/kernel_stats.csv" \;
 pmc() {   # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$OUT/pmc_$name" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --frame-loop-steps 0 --as-shipped-steps 0 --no-kernel-events --reps 0 $BENCH_ARGS > /dev/null 2> "$R/$OUT/pmc_$name.err"
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$OUT/pmc_$name" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs --frame-loop-steps 0 --as-shipped-steps 0 --no-kernel-events --reps 0 $BENCH_ARGS > /dev/null 2> "$R/$OUT/pmc_$name.err"
     find "$R/$OUT/pmc_$name" -name "*counter_collection.csv" -exec cp {} "$R/$OUT/pmc_$name.csv" \;
     rm -rf "$R/$OUT/pmc_$name"
 }
