@@ -1277,64 +1277,39 @@ bool resident_eligible(const lutldpc_decoder *d) {
     return resident_lds_bytes(R) <= kLdsPerCu - 2048;
 }
 
-// Sets per workgroup and workgroup size for a batch of G frame groups: the cheapest of the configurations that fit.
-// Model (fitted to tools/resident_probe.py runs on MI355X): a compute unit holds as many workgroups as LDS (S * E dwords + tables)
-// and the register file (estimated registers per thread) allow; several small workgroups per compute unit beat one large one
-// (their check and variable phases interleave: (6,32) N=2048 23.6 M codewords/s at S = 1 / 512 threads against 19.0 M at S = 2 /
-// 1024), few waves per compute unit hide the LDS latency badly, and every pass of a workgroup costs two barriers and a table
-// staging whatever its size (N=500: S = 8 beats S = 2 by 1.5x).
+// Sets per workgroup (S) and workgroup size (NT) for a batch of G frame groups.  Rules read off tools/resident_probe.py sweeps on
+// MI355X (profiles/r03_resident_geometry_sweep.txt):
+//   * two or three workgroups per compute unit beat one large one -- their check and variable phases interleave on the vector
+//     ALUs and the LDS: (6,32) N=2048 23.6 M codewords/s at S = 1 / 512 threads (three workgroups of 51 KB) against 19.3 M at
+//     S = 2 / 1024 -- so S is the largest value that leaves room for two workgroups (<= 78 KB of LDS each) ...
+//   * ... and gives a thread about eight variable-node items: every pass of a workgroup costs two barriers and a table staging
+//     whatever its size, and the items of a heavy degree class spread evenly only when there are many (N=500: 13.3 M at
+//     S = 8 / 512, 9.4 M at S = 2 / 256, 6.2 M at S = 2 / 1024);
+//   * a code that fills the LDS with a single set ((3,6) N=10000: 120 KB) runs one workgroup of 1024 threads;
+//   * a batch too small to give every compute unit its workgroups takes a smaller S.
+// LUTLDPC_RESIDENT_S / LUTLDPC_RESIDENT_NT override.
 bool resident_pick(const lutldpc_decoder *d, int G, int &S_out, int &NT_out, int &lds_out) {
-    int max_vn = 0, max_cn = 0;
-    for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
-    for (auto &c : d->cclass) max_cn = std::max(max_cn, c.deg);
     const long long sets = 64ll * G;
-    const int F = 4 * d->pack;
-    // work of one item in instruction-equivalents (look-ups from the node programs of tree set 0)
-    std::vector<double> wv(d->vclass.size()), wc(d->cclass.size());
-    double wmax = 0;
-    for (size_t i = 0; i < d->vclass.size(); i++) {
-        size_t ops = 0;
-        for (size_t s = 0; s < d->var_prog_c.size() && !ops; s++) if (i < d->var_prog_c[s].size()) ops = d->var_prog_c[s][i].ops.size();
-        wv[i] = F * (2.0 * d->vclass[i].deg + 1 + 2.0 * (double)ops) + 3.0 * d->vclass[i].deg + 20;
-        wmax = std::max(wmax, wv[i]);
+    auto lds_of = [&](int S, int NT) { return resident_lds_bytes(resident_spec(d, S, NT)); };
+    auto items_of = [&](int S, int NT) { return (int)((S * (long long)d->nvar + NT - 1) / NT) + (int)d->vclass.size(); };
+    const int budget = kLdsPerCu - 2048;
+    if (lds_of(1, 512) > budget) return false;
+    int S = 1, NT = 512;
+    if (d->resident_force_S || d->resident_force_NT) {
+        S = d->resident_force_S ? d->resident_force_S : 1;
+        NT = d->resident_force_NT ? d->resident_force_NT : 512;
+    } else if (lds_of(1, 512) > 78 * 1024) {
+        NT = 1024;                                              // one workgroup per compute unit: all the waves it can hold
+    } else {
+        while (S < 64 && lds_of(S + 1, NT) <= 78 * 1024 && (S + 1) * (long long)d->nvar <= 8ll * NT + NT / 2) S++;
+        while (S > 1 && (sets + S - 1) / S < (long long)kResidentCus) S--;        // small batch: at least one workgroup per compute unit
     }
-    for (size_t i = 0; i < d->cclass.size(); i++) {
-        size_t ops = 0;
-        if (!d->min_lut) for (size_t s = 0; s < d->chk_prog_c.size() && !ops; s++) if (i < d->chk_prog_c[s].size()) ops = d->chk_prog_c[s][i].ops.size();
-        const int dg = d->cclass[i].deg;
-        wc[i] = d->min_lut ? (dg <= 16 ? 16.0 * dg : 30.0 * dg) + 16 : F * (3.0 * dg + 2.5 * (double)ops) + 4.0 * dg;
-        wmax = std::max(wmax, wc[i]);
+    while (S > 1 && (lds_of(S, NT) > budget || items_of(S, NT) > 46)) S--;
+    if (lds_of(S, NT) > budget || items_of(S, NT) > 46) {
+        if (NT < 1024 && items_of(S, 1024) <= 46 && lds_of(S, 1024) <= budget) NT = 1024; else return false;
     }
-    double best = 1e300; bool found = false;
-    for (int NT : {1024, 768, 512, 256}) {
-        if (d->resident_force_NT && NT != d->resident_force_NT) continue;
-        for (int S = 1; S <= 64; S++) {
-            if (d->resident_force_S && S != d->resident_force_S) continue;
-            const ResidentSpec R = resident_spec(d, S, NT);
-            const int lds = resident_lds_bytes(R);
-            if (lds > kLdsPerCu - 2048) break;
-            const int ipt = (int)((S * (long long)d->nvar + NT - 1) / NT) + (int)d->vclass.size();
-            if (ipt > 46) break;
-            const double vgpr = 30 + 3.0 * ipt + 2.0 * max_vn + (d->min_lut ? (max_cn <= 16 ? 3.0 * max_cn : 16.0) : 3.0 * max_cn);
-            int waves_simd = std::min(8, (int)(512.0 / vgpr));
-            if (NT == 1024 && vgpr <= 140) waves_simd = std::max(waves_simd, 4);       // __launch_bounds__(1024) holds the compiler to 128 registers
-            const int threads_cu = std::min(2048, waves_simd * 256);
-            if (NT > threads_cu && !(d->resident_force_NT || d->resident_force_S)) continue;
-            const int bpc = std::max(1, std::min(kLdsPerCu / (lds + 512), threads_cu / NT));
-            double W = 0;
-            for (size_t i = 0; i < d->vclass.size(); i++) W += S * (double)d->vclass[i].nodes.size() * wv[i];
-            for (size_t i = 0; i < d->cclass.size(); i++) W += S * (double)d->cclass[i].nodes.size() * wc[i];
-            std::vector<int> a, b; int tvb, tcb;
-            resident_table_bytes(R, a, tvb, b, tcb);
-            const double load = W / NT + wmax + 350.0 + 2.0 * (tvb + tcb) / 4.0 / NT;     // per pass pair: imbalance, barriers, staging
-            const long long blocks = (sets + S - 1) / S;
-            const long long rounds = (blocks + (long long)kResidentCus * bpc - 1) / ((long long)kResidentCus * bpc);
-            const double waves = (double)bpc * NT / 64.0, util = std::min(1.0, 0.4 + waves / 40.0) * (bpc >= 2 ? 1.0 : 0.85);
-            const double t = (double)rounds * bpc * load / util;
-            if (t < best) { best = t; S_out = S; NT_out = NT; lds_out = lds; found = true; }
-        }
-    }
-    return found;
+    S_out = S; NT_out = NT; lds_out = lds_of(S, NT);
+    return true;
 }
 
 bool resident_active(const lutldpc_decoder *d) { return d->resident_ok && d->use_resident; }
