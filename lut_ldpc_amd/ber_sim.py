@@ -71,7 +71,7 @@ def _prefix_until_stop(stats: np.ndarray, K: int, nfers: int, ferr_before: int):
 
 
 def sim_snr_point_sharded(batch_fn: Callable[[int, int], np.ndarray], nframes: int, nfers: int, K: int, comm: Comm,
-                          batch_max: int = 4096, batch_first: int = 256):
+                          batch_max: int = 4096, batch_first: int = 512):
     """Frame loop of sim_snr_point (src/LDPC_BER_Sim.cpp:260-291) over `comm.world` ranks.
 
     batch_fn(frame0, B) -> int array [B, 4] = {iters, frame error, data bit errors, uncoded errors} of

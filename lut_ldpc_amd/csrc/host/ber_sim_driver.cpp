@@ -13,6 +13,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <cstdlib>
 
 namespace fs = std::filesystem;
 
@@ -149,7 +150,7 @@ LDPC_BER_Sim::LDPC_BER_Sim(const std::string &params, const std::string &base) :
     // build-side: upper bound of the frames per device call.  32768 is the measured optimum on MI355X for the N = 64800 codes
     // (+7 % over 4096: launch tails weigh less; +3 % over 16384 with early termination: two halves of 32 frame groups, the most
     // the compaction of the surviving frames takes; 6.8 GB of rows) and costs the short codes nothing; the frame loop still
-    // starts at 256 frames and quadruples (sim_snr_point), so a point that stops after Nfers errors wastes little work
+    // starts at 512 frames (one frame group) and quadruples (sim_snr_point), so a point that stops after Nfers errors wastes little work
     batch_frames = ini.get("Sim.batch_frames", 32768);
     codes_path = join(base, codes_dir);
     results_path = join(base, results_dir);
@@ -328,7 +329,7 @@ bool LDPC_BER_Sim::sim_snr_point(double snr, int snr_index) {
     SnrPointCounters c;
     const int64_t total = (int64_t)Nframes;
     int64_t f = 0;
-    int batch = std::min(256, batch_frames);
+    int batch = std::min(512, batch_frames);            // one full frame group of nibble rows (a 256-frame start ran half-empty groups)
     std::vector<FrameStats> stats;
     while (f < total) {
         const int B = (int)std::min<int64_t>(batch, total - f);
@@ -463,7 +464,9 @@ void LDPC_BER_Sim_BP::sim_batch(double snr, int snr_index, int64_t frame0, int B
 
 // ------------------------------------------------------------------ ber_sim main
 int ber_sim_main(int argc, char **argv) {
-    int seed = 0, device = 0;
+    int seed = 0, device = 0, lanes = 2;
+    std::vector<int> devices;
+    std::string exchange = "auto";
     std::string base_dir = fs::current_path().string(), custom_name, params;
     bool have_params = false;
     auto usage = [] {
@@ -473,7 +476,11 @@ int ber_sim_main(int argc, char **argv) {
                      "  -h [ --help ]             produce help message\n"
                      "  -p [ --params ] arg       input parameter file\n"
                      "  -s [ --seed ] arg (=0)    random seed\n"
-                     "  -d [ --device ] arg (=0)  HIP device ordinal (build-side option)\n";
+                     "  -d [ --device ] arg (=0)  HIP device ordinal, a list 0,1,2,3 or `all`: the frames of every SNR point are sharded\n"
+                     "                            over the devices, counters over RCCL (build-side option)\n"
+                     "  --lanes arg (=2)          host threads (simulation objects, streams) per device: batches of one overlap the\n"
+                     "                            sampler / transfers of the other; 1 = the plain synchronous loop\n"
+                     "  --exchange arg (=auto)    rccl | host | auto: how the counters of the ranks are combined\n";
     };
     try {
         for (int i = 1; i < argc; i++) {
@@ -490,7 +497,22 @@ int ber_sim_main(int argc, char **argv) {
             else if (value("-c", "--custom-name", v)) custom_name = v;
             else if (value("-p", "--params", v)) { params = v; have_params = true; }
             else if (value("-s", "--seed", v)) seed = std::stoi(v);
-            else if (value("-d", "--device", v)) device = std::stoi(v);
+            else if (value("-d", "--device", v)) {
+                devices.clear();
+                if (v == "all") {
+                    const int n = lutldpc_device_count();
+                    for (int i = 0; i < n; i++) devices.push_back(i);
+                    if (devices.empty()) throw std::runtime_error("no HIP device visible");
+                } else {
+                    std::stringstream ss(v);
+                    std::string tok;
+                    while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(std::stoi(tok));
+                    if (devices.empty()) throw std::runtime_error("empty device list");
+                }
+                device = devices[0];
+            }
+            else if (value("--lanes", "--lanes", v)) lanes = std::stoi(v);
+            else if (value("--exchange", "--exchange", v)) exchange = v;
             else throw std::runtime_error("unrecognised option '" + a + "'");
         }
     } catch (const std::exception &e) {
@@ -504,6 +526,12 @@ int ber_sim_main(int argc, char **argv) {
         if (!fs::exists(params_path)) throw std::runtime_error("Parameter file" + params_path + " does not exist!");
         Ini ini(params_path);
         const std::string codec_type = ini.get("Sim.codec_type", "none");
+        if (devices.empty()) devices.push_back(device);
+        if (const char *e = std::getenv("LUTLDPC_LANES")) lanes = std::atoi(e);
+        const bool is_bp = !(ini.has_section("LUT") || codec_type == "LUT");
+        if (is_bp && devices.size() == 1) lanes = 1;               // (the [BP] comparison decoder draws its noise on all host cores already)
+        if (devices.size() > 1 || lanes > 1)
+            return ber_sim_run_multi(params_path, base_dir, seed, custom_name, devices, lanes, exchange, false);
         std::unique_ptr<LDPC_BER_Sim> sim;
         if (ini.has_section("LUT") || codec_type == "LUT") sim.reset(new LDPC_BER_Sim_LUT(params_path, base_dir));
         else if (ini.has_section("BP") || codec_type == "BP") sim.reset(new LDPC_BER_Sim_BP(params_path, base_dir));

@@ -147,6 +147,12 @@ private:
     lutldpc_bp_decoder *dec = nullptr;
 };
 
+// One run of a parameter file over several devices of a node (ber_sim_multi.cpp): `lanes` host threads per device, each with its
+// own simulation object / decoder handle / stream; frames sharded by rank, counters exchanged over RCCL ("rccl"), on the host
+// ("host": ranks may share a device) or whichever applies ("auto").  Writes the same result file as the single-device run.
+int ber_sim_run_multi(const std::string &params_path, const std::string &base_dir, int seed, const std::string &custom_name,
+                      const std::vector<int> &devices, int lanes, const std::string &exchange_mode, bool quiet);
+
 // ber_sim's main (prog/ber_sim.cpp:46-160): returns the process exit code
 int ber_sim_main(int argc, char **argv);
 

@@ -9,6 +9,7 @@
  * within the HIP limits, no launch with a NULL function.  Nothing in lut_ldpc_amd/ knows about this file:
  * the ASan build of the library is linked against it instead of libamdhip64 (hiprtc stays the real one).
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +21,12 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 
 static hipError_t g_last = 0;
 static long g_launches = 0, g_allocs = 0, g_frees = 0, g_live_bytes = 0, g_graph_launches = 0, g_captures = 0;
-static int g_capturing = 0;
+static __thread int g_capturing = 0;            /* a capture belongs to the stream of one host thread (hipStreamCaptureModeThreadLocal) */
+/* several host threads drive "devices" at once in the multi-device ber_sim (ber_sim_multi.cpp): the shim's tables are shared */
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+#define LOCK() pthread_mutex_lock(&g_mu)
+#define UNLOCK() pthread_mutex_unlock(&g_mu)
+static int fake_device_count(void) { const char *e = getenv("FAKEHIP_DEVICES"); int n = e ? atoi(e) : 1; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 #define MAX_FUNCS 4096
 static struct { const void *host; char name[200]; } g_funcs[MAX_FUNCS];
@@ -55,8 +61,8 @@ long fakehip_launches_of(const char *substr)
 void fakehip_reset_counters(void) { g_launches = 0; g_graph_launches = 0; g_captures = 0; memset(g_by_func, 0, sizeof g_by_func); }
 
 /* ---- device / stream */
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : fail("hipSetDevice: no such device"); }
+hipError_t hipGetDeviceCount(int *n) { *n = fake_device_count(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { return (d >= 0 && d < fake_device_count()) ? hipSuccess : fail("hipSetDevice: no such device"); }
 hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = 0; return e; }
 const char *hipGetErrorString(hipError_t e) { return e ? "fake_hip error" : "no error"; }
 hipError_t hipStreamCreateWithFlags(void **s, unsigned flags) { (void)flags; *s = malloc(16); return hipSuccess; }
@@ -71,22 +77,28 @@ hipError_t hipMalloc(void **p, size_t n)
     *p = malloc(n);
     if (!*p) return hipErrorOutOfMemory;
     memset(*p, 0xA5, n);                 /* device memory is NOT zeroed by hipMalloc: poison it */
-    if (g_nlive >= MAX_LIVE) return fail("fake_hip: live table full");
+    LOCK();
+    if (g_nlive >= MAX_LIVE) { UNLOCK(); return fail("fake_hip: live table full"); }
     g_live[g_nlive].p = *p; g_live[g_nlive].n = n; g_nlive++;
     g_allocs++; g_live_bytes += (long)n;
+    UNLOCK();
     return hipSuccess;
 }
 hipError_t hipFree(void *p)
 {
     if (!p) return hipSuccess;
     if (g_capturing) return fail("hipFree during stream capture");
+    LOCK();
     for (int i = 0; i < g_nlive; i++)
         if (g_live[i].p == p) {
             g_live_bytes -= (long)g_live[i].n;
             g_live[i] = g_live[--g_nlive];
-            free(p); g_frees++;
+            g_frees++;
+            UNLOCK();
+            free(p);
             return hipSuccess;
         }
+    UNLOCK();
     return fail("hipFree of a pointer hipMalloc never returned (or double free)");
 }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, int kind)
@@ -126,7 +138,7 @@ void __hipRegisterFunction(void **m, const void *host, char *dev, const char *na
 void __hipRegisterVar(void **m, void *var, char *a, const char *b, int ext, size_t size, int constant, int global)
 { (void)m; (void)var; (void)a; (void)b; (void)ext; (void)size; (void)constant; (void)global; }
 
-static struct { dim3_t g, b; size_t shmem; void *stream; } g_cfg;
+static __thread struct { dim3_t g, b; size_t shmem; void *stream; } g_cfg;
 hipError_t __hipPushCallConfiguration(dim3_t g, dim3_t b, size_t shmem, void *stream) { g_cfg.g = g; g_cfg.b = b; g_cfg.shmem = shmem; g_cfg.stream = stream; return hipSuccess; }
 hipError_t __hipPopCallConfiguration(dim3_t *g, dim3_t *b, size_t *shmem, void **stream) { *g = g_cfg.g; *b = g_cfg.b; *shmem = g_cfg.shmem; *stream = g_cfg.stream; return hipSuccess; }
 
@@ -145,9 +157,11 @@ hipError_t hipLaunchKernel(const void *func, dim3_t g, dim3_t b, void **args, si
     hipError_t e = check_geometry(g.x, g.y, g.z, b.x, b.y, b.z, shmem);
     if (e) return e;
     int known = 0;
+    LOCK();
     for (int i = 0; i < g_nfuncs; i++) if (g_funcs[i].host == func) { g_by_func[i]++; known = 1; break; }
+    g_launches += known;
+    UNLOCK();
     if (!known) return fail("hipLaunchKernel: function was never registered");
-    g_launches++;
     return hipSuccess;
 }
 hipError_t hipFuncGetAttributes(void *attr, const void *func)
@@ -173,14 +187,14 @@ hipError_t hipModuleLaunchKernel(void *f, unsigned gx, unsigned gy, unsigned gz,
     if (!f || !params) return fail("hipModuleLaunchKernel: NULL function or parameters");
     hipError_t e = check_geometry(gx, gy, gz, bx, by, bz, shmem);
     if (e) return e;
-    g_launches++;
+    LOCK(); g_launches++; UNLOCK();
     return hipSuccess;
 }
 
 /* ---- graphs */
-hipError_t hipStreamBeginCapture(void *s, int mode) { (void)s; (void)mode; if (g_capturing) return fail("nested capture"); g_capturing = 1; g_captures++; return hipSuccess; }
+hipError_t hipStreamBeginCapture(void *s, int mode) { (void)s; (void)mode; if (g_capturing) return fail("nested capture"); g_capturing = 1; LOCK(); g_captures++; UNLOCK(); return hipSuccess; }
 hipError_t hipStreamEndCapture(void *s, void **graph) { (void)s; if (!g_capturing) return fail("EndCapture without BeginCapture"); g_capturing = 0; *graph = malloc(8); return hipSuccess; }
 hipError_t hipGraphInstantiate(void **exec, void *graph, void *a, void *b, size_t c) { (void)a; (void)b; (void)c; if (!graph) return fail("instantiate NULL graph"); *exec = malloc(8); return hipSuccess; }
 hipError_t hipGraphDestroy(void *g) { free(g); return hipSuccess; }
 hipError_t hipGraphExecDestroy(void *e) { free(e); return hipSuccess; }
-hipError_t hipGraphLaunch(void *e, void *s) { (void)s; if (!e) return fail("hipGraphLaunch(NULL)"); g_graph_launches++; return hipSuccess; }
+hipError_t hipGraphLaunch(void *e, void *s) { (void)s; if (!e) return fail("hipGraphLaunch(NULL)"); LOCK(); g_graph_launches++; UNLOCK(); return hipSuccess; }

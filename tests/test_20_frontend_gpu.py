@@ -192,3 +192,31 @@ def test_config4_two_ranks_sharing_the_gpu_equal_one_rank(tmp_path):
     for k in ("sim_SNRdB", "sim_Nframes", "sim_Ndatabits", "sim_frame_errors", "sim_data_bit_errors", "sim_uncoded_bit_errors"):
         assert a[k].tolist() == b[k].tolist(), k
     assert sum(a["sim_Nframes"].tolist()) > 1500
+
+
+def test_cpp_multi_rank_ber_sim_equals_the_single_rank_result_file(tmp_path):
+    """The native multi-device ber_sim (ber_sim_multi.cpp) on the one GPU of the box: ranks that SHARE the device (`-d 0,0,0`: three
+    ranks, counters combined on the host -- RCCL refuses ranks on one device) and the default two lanes on one device write the
+    same result file as the plain single-rank loop: Philox-addressed frames + the stop rule applied in global frame order
+    (src/LDPC_BER_Sim.cpp:289).  Nframes is raised so that several rounds of several ranks happen and low-SNR points stop early
+    in the middle of a round."""
+    base = _setup_basedir(tmp_path)
+    ini = (ROOT / "data" / "params" / "ber.ini.irregular.example").read_text().replace("Nframes  = 1e2", "Nframes  = 7000\n   batch_frames = 1024")
+    params = tmp_path / "ber_multi.ini"
+    params.write_text(ini)
+    exe = ROOT / "lut_ldpc_amd" / "lib" / "ber_sim"
+    files = {}
+    for tag, extra in (("_one", ["-d", "0", "--lanes", "1"]), ("_lanes", ["-d", "0"]), ("_three", ["-d", "0,0,0", "--lanes", "1", "--exchange", "host"])):
+        r = subprocess.run([str(exe), "-p", str(params), "-b", str(base), "-s", "4", "-c", tag] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        out = sorted((base / "results").glob(f"*{tag}/*_rseed0004.it"))
+        assert len(out) == 1
+        files[tag] = itload(out[0])
+        if tag != "_one":
+            assert "counters over the host" in r.stdout, r.stdout[-500:]
+    a = files["_one"]
+    assert a["sim_Nframes"][0] < 7000 and a["sim_frame_errors"][0] == 21             # 0 dB: stops after Nfers + 1 frame errors
+    assert a["sim_Nframes"].max() == 7000                                             # a high-SNR point runs to Nframes
+    for tag in ("_lanes", "_three"):
+        for k in ("sim_SNRdB", "sim_Nframes", "sim_Ndatabits", "sim_frame_errors", "sim_data_bit_errors", "sim_uncoded_bit_errors"):
+            assert (np.asarray(files[tag][k]) == np.asarray(a[k])).all(), (tag, k, files[tag][k], a[k])
