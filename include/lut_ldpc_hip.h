@@ -93,6 +93,14 @@ int lutldpc_decoder_decode_batch(lutldpc_decoder *d, const uint8_t *cha, const u
 int lutldpc_decoder_decode_batch_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B,
                                         uint8_t *d_out_bits, int32_t *d_out_iters, int sync);
 
+/* lut_decode of a small batch with the message dumps of LDPC_Code_LUT::set_output_verbosity(level), level 2 or 3
+ * (src/LDPC_Code_LUT.cpp:292-298 initial messages, :311-317 after every check update (level 3), :331-337 after every variable
+ * update): trace[dump][B][E] label bytes in the reference's print order, *n_dumps = 1 + max_iters * (level - 1).  Debug path
+ * (per-class streaming launches, one copy per dump); which dumps the reference would have PRINTED for a frame follows from its
+ * iteration code (a frame that leaves through the exit test returns before the dump of its last variable update). */
+int lutldpc_decoder_decode_batch_trace(lutldpc_decoder *d, const uint8_t *cha, const uint8_t *msg0, int B, int level, uint8_t *out_bits,
+                                       int32_t *out_iters, uint8_t *trace, int64_t trace_cap, int32_t *n_dumps);
+
 /*
  * Batched LDPC_Code_LUT::decode(const vec&, bvec&) (src/LDPC_Code_LUT.cpp:204-226):
  * quant_nonlin with the boundaries qb_Cha / qb_Msg (src/common.cpp:120-138), initial

@@ -56,6 +56,11 @@ lutldpc_decoder *lutldpc_codec_decoder(lutldpc_codec *c);
 /* batched LDPC_Code_LUT::decode / lut_decode (host buffers, all nvar bits per frame) */
 int lutldpc_codec_decode_llr_batch(lutldpc_codec *c, const double *llr, int B, uint8_t *bits, int32_t *iters);
 int lutldpc_codec_lut_decode_batch(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters);
+/* lut_decode with LDPC_Code_LUT::set_output_verbosity(level), level 2 or 3: the message dumps of src/LDPC_Code_LUT.cpp:292-298,
+ * 311-317, 331-337 as text, frame after frame (what the reference streams to std::cout).  Returns the bytes needed for the text
+ * including the terminating NUL (buf may be NULL / too small: nothing is copied then), or a negative error code. */
+int64_t lutldpc_codec_lut_decode_dump(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, int level, uint8_t *bits, int32_t *iters,
+                                      char *buf, int64_t cap);
 /* LDPC_Code_LUT::encode: info[K] -> codeword[nvar] (needs with_generator) */
 int lutldpc_codec_encode(lutldpc_codec *c, const uint8_t *info, uint8_t *codeword);
 
@@ -96,6 +101,9 @@ int64_t lutldpc_bersim_results_path(lutldpc_bersim *s, char *buf, int64_t cap);
 
 /* the command line itself */
 int lutldpc_ber_sim_main(int argc, char **argv);
+/* the results file of src/LDPC_BER_Sim.cpp:342-362 for given counters (n SNR points x {frames, data bits, frame errors, data bit errors,
+ * uncoded bit errors}): the writer behind ber_sim's result files, exposed for its byte-level known-answer test */
+int lutldpc_selftest_write_results_it(const char *path, const double *snr, const int64_t *counters, int n, int nvar, int nchk, double runtime);
 
 /* LDPC_DE_LUT::bisec_search for an ensemble given by its active degrees (prog/de_sim.cpp:137-260
  * set-up: auto trees, no reuse, uniform resolution).  Returns the bisection count, <0 on error. */

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "lutldpc_decoder_describe": (_cp, [_vp]),
     "lutldpc_selftest_program_eval": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int]),
     "lutldpc_selftest_program_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),
+    "lutldpc_decoder_decode_batch_trace": (C.c_int, [_vp, _u8p, _u8p, C.c_int, C.c_int, _u8p, _ip, _u8p, C.c_int64, _ip]),
     "lutldpc_selftest_jit_source": (C.c_int64, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int]),
     "lutldpc_selftest_resident_source": (C.c_int64, [_vp, C.c_int, C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
 }
@@ -98,6 +99,7 @@ _HOST_SIGNATURES = {
     "lutldpc_codec_decoder": (_vp, [_vp]),
     "lutldpc_codec_decode_llr_batch": (C.c_int, [_vp, _dp, C.c_int, _u8p, _ip]),
     "lutldpc_codec_lut_decode_batch": (C.c_int, [_vp, _u8p, _u8p, C.c_int, _u8p, _ip]),
+    "lutldpc_codec_lut_decode_dump": (C.c_int64, [_vp, _u8p, _u8p, C.c_int, C.c_int, _u8p, _ip, C.c_char_p, C.c_int64]),
     "lutldpc_codec_encode": (C.c_int, [_vp, _u8p, _u8p]),
     "lutldpc_de_threshold": (C.c_int, [_ip, _dp, C.c_int, _ip, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _cp, _cp, C.c_double,
                                        C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, _dp]),
@@ -114,6 +116,7 @@ _SIM_SIGNATURES = {
     "lutldpc_codec_channel_cells": (C.c_int, [_vp, C.c_double, _u64p, _u8p, _u8p, _u8p, _u8p, _u8p]),
     "lutldpc_ber_sim_run": (C.c_int, [_cp, _cp, C.c_int, _cp, C.c_int, C.c_int, C.c_int, _dp, _i64p, C.c_int]),
     "lutldpc_ber_sim_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "lutldpc_selftest_write_results_it": (C.c_int, [_cp, _dp, _i64p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "lutldpc_bersim_create": (C.c_int, [_cp, _cp, C.c_int, _cp, C.c_int, C.POINTER(_vp)]),
     "lutldpc_bersim_destroy": (C.c_int, [_vp]),
     "lutldpc_bersim_info": (C.c_int, [_vp, _i64p, _dp, _dp, C.c_int]),

@@ -124,6 +124,20 @@ class Codec:
         check(lib.lutldpc_codec_decode_llr_batch(self._h, _p(llr, C.c_double), B, _p(bits, C.c_uint8), _p(iters, C.c_int32)))
         return bits, iters
 
+    def lut_decode_dump(self, cha, msg0, level=2):
+        """lut_decode with output_verbosity = level (2 or 3): (bits, iters, text of the message dumps as the reference prints them)."""
+        cha = np.ascontiguousarray(cha, np.uint8); msg0 = np.ascontiguousarray(msg0, np.uint8)
+        B = cha.shape[0]
+        bits = np.empty_like(cha); iters = np.empty(B, np.int32)
+        n = lib.lutldpc_codec_lut_decode_dump(self._h, _p(cha, C.c_uint8), _p(msg0, C.c_uint8), B, int(level), _p(bits, C.c_uint8), _p(iters, C.c_int32), None, 0)
+        if n < 0:
+            check(int(n))
+        buf = C.create_string_buffer(n)
+        n2 = lib.lutldpc_codec_lut_decode_dump(self._h, _p(cha, C.c_uint8), _p(msg0, C.c_uint8), B, int(level), _p(bits, C.c_uint8), _p(iters, C.c_int32), buf, n)
+        if n2 < 0:
+            check(int(n2))
+        return bits, iters, buf.value.decode()
+
     def lut_decode_batch(self, cha, msg0):
         cha = np.ascontiguousarray(cha, np.uint8)
         msg0 = np.ascontiguousarray(msg0, np.uint8)

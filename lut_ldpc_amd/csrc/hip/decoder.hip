@@ -149,6 +149,12 @@ struct lutldpc_decoder {
     int compact_keep = 1;                                           // LUTLDPC_COMPACT_KEEP: the frames that left keep their rows, bits recovered once at the end
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     DevBuf<int32_t> d_grp;                           // per frame group: every frame failed the probe of the test on the channel decisions
+    // message dumps of output_verbosity >= 2 (src/LDPC_Code_LUT.cpp:292-298,311-317,331-337): a small-batch debug path -- per-class
+    // streaming launches, the edge rows copied out after the edge initialisation, (level > 2) every check pass and every
+    // variable pass.  host: [dump][B][E] bytes, dumps in the reference's print order.
+    struct Trace { int level = 0; uint8_t *host = nullptr; size_t cap = 0; int n = 0; int B = 0; };
+    Trace trace;
+    DevBuf<uint8_t> d_trace;
     // LDS-resident decoder (jit_resident.hpp): codes whose edge messages fit the LDS of a compute unit are decoded by ONE generated
     // kernel per decode -- all iterations inside, no HBM traffic between the labels and the decided bits.  LUTLDPC_RESIDENT=0: off
     // (the streaming kernels run instead); LUTLDPC_RESIDENT_S / _NT force the sets per workgroup / threads per workgroup.
@@ -779,8 +785,8 @@ int launch_transpose_in(lutldpc_decoder *d, const uint8_t *src, uint8_t *dst_row
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
-int launch_transpose_out(lutldpc_decoder *d, const uint8_t *src_rows, uint8_t *dst, int B, int G) {
-    const int N = d->nvar;
+int launch_transpose_out(lutldpc_decoder *d, const uint8_t *src_rows, uint8_t *dst, int B, int G, int rows = 0) {
+    const int N = rows > 0 ? rows : d->nvar;
     if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
         PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
     else
@@ -1359,6 +1365,21 @@ int launch_resident(lutldpc_decoder *d, int G) {
     return LUTLDPC_OK;
 }
 
+// one message dump of the trace: the E edge rows of all frames, frame-major, to the next slot of the host buffer (synchronous)
+int trace_dump(lutldpc_decoder *d) {
+    lutldpc_decoder::Trace &T = d->trace;
+    const size_t one = (size_t)T.B * (size_t)d->E;
+    if ((size_t)(T.n + 1) * one > T.cap) return fail(LUTLDPC_ERR_ARG, "trace buffer too small");
+    const int G = d->bpad(T.B) / d->tile();
+    HIP_TRY(d->d_trace.alloc(one));
+    if (int rc = launch_transpose_out(d, d->d_msgs.p, d->d_trace.p, T.B, G, d->E)) return rc;
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(T.host + (size_t)T.n * one, d->d_trace.p, one, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    T.n++;
+    return LUTLDPC_OK;
+}
+
 // Core: decode the B frames whose labels are already in tile layout (d_cha_t / d_msg0_t).
 // Leaves the decided bits in d_hard (tile layout) and the iteration codes in d_iters.
 int decode_tiles_launch(lutldpc_decoder *d, int B) {
@@ -1369,7 +1390,8 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     if (!d->dec_plan[(size_t)last_set].valid)
         return fail(LUTLDPC_ERR_STATE, "the tree set of iteration max_iters-1 is not a decision tree set");
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
-    if (resident_active(d)) {                     // the whole of lut_decode in one launch, messages in LDS (jit_resident.hpp)
+    const bool tracing = d->trace.level > 1;
+    if (resident_active(d) && !tracing) {         // the whole of lut_decode in one launch, messages in LDS (jit_resident.hpp)
         if ((rc = launch_resident(d, G))) return rc;
         if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
         return LUTLDPC_OK;
@@ -1396,12 +1418,13 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
             LAUNCH_CHECK();
         }
     }
-    const bool skewed = d->skew && d->skew_ok;      // (a single frame group runs the same launches with an empty second half)
+    const bool skewed = d->skew && d->skew_ok && !tracing;      // (a single frame group runs the same launches with an empty second half)
     if (!(skewed && d->first_from_nodes)) {   // :284-289 (the fused pipeline's first check pass reads the initial-message rows itself)
         Timed t(d, LUTLDPC_K_LAYOUT);
         hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
         LAUNCH_CHECK();
     }
+    if (tracing && (rc = trace_dump(d))) return rc;                              // :292-298
     if (skewed && (rc = iterate_skewed(d, B, Bpad, G))) return rc;
     for (int ii = 0; ii < I && !skewed; ii++) {   // :301-338
         const int set = d->iter_set[(size_t)ii];
@@ -1411,12 +1434,14 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, d->chk_jit.empty() ? nullptr : &d->chk_jit[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
         if (rc) return rc;
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
+        if (d->trace.level > 2 && (rc = trace_dump(d))) return rc;             // :311-317
         if (ii != I - 1) {
             const int nz_out = d->Nq_Msg[(size_t)(ii + 1)] / 2;
             rc = launch_tree_pass<TT_VAR>(d, d->var_plan[(size_t)set], &d->var_fast[(size_t)set], d->var_jit.empty() ? nullptr : &d->var_jit[(size_t)set], G, nz_out, d->psc ? 1 : 0,
                                           (d->psc && !late_hard_active(d, false, nullptr)) ? 1 : 0, LUTLDPC_K_VN_PASS);
             if (rc) return rc;
         }
+        if (tracing && (rc = trace_dump(d))) return rc;                         // :331-337 (printed after the last iteration too)
     }
     {   // decided bits of the frames that left through the exit test, from their frozen messages (see late_hard_active)
         Timed t(d, LUTLDPC_K_LAYOUT);
@@ -1452,7 +1477,7 @@ int decode_tiles(lutldpc_decoder *d, int B) {
         lutldpc_decoder::ResidentPlan *pl = nullptr;
         if (int rc = resident_plan_for(d, d->bpad(B) / d->tile(), &pl)) return rc;
     }
-    if (!d->use_graph || d->profiling) return decode_tiles_launch(d, B);
+    if (!d->use_graph || d->profiling || d->trace.level > 1) return decode_tiles_launch(d, B);
     const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
     if (d->graphs.size() > 32 && !d->graphs.count(key)) d->drop_graphs();      // callers with ever-changing batch sizes: bound the cache
     auto &slot = d->graphs[key];
@@ -1691,7 +1716,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->drop_graphs();
         d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release(); d->d_grp.release();
         d->drop_plans();
-        d->d_out_iters.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
+        d->d_out_iters.release(); d->d_trace.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
     }
     delete d;
@@ -1731,6 +1756,22 @@ int lutldpc_decoder_decode_batch(lutldpc_decoder *d, const uint8_t *cha, const u
     HIP_TRY(hipMemcpyAsync(out_iters, d->d_out_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     return LUTLDPC_OK;
+}
+
+// lut_decode of a small batch with the message dumps of output_verbosity = level (2: initial + after every variable update,
+// 3: after every check update as well): trace[dump][B][E] label bytes in the reference's print order, n_dumps = 1 + I * (level - 1).
+int lutldpc_decoder_decode_batch_trace(lutldpc_decoder *d, const uint8_t *cha, const uint8_t *msg0, int B, int level, uint8_t *out_bits, int32_t *out_iters,
+                                       uint8_t *trace, int64_t trace_cap, int32_t *n_dumps) {
+    if (!d || !cha || !msg0 || !out_bits || !out_iters || !trace) return fail(LUTLDPC_ERR_ARG, "NULL argument");
+    if (level < 2 || level > 3) return fail(LUTLDPC_ERR_ARG, "trace level must be 2 or 3");
+    if (B <= 0 || B > 4096) return fail(LUTLDPC_ERR_ARG, "the message trace is a debug path: 1..4096 frames");
+    const int64_t need = (int64_t)(1 + d->max_iters * (level - 1)) * B * d->E;
+    if (trace_cap < need) return fail(LUTLDPC_ERR_ARG, "trace buffer too small: " + std::to_string(need) + " bytes needed");
+    d->trace.level = level; d->trace.host = trace; d->trace.cap = (size_t)trace_cap; d->trace.n = 0; d->trace.B = B;
+    const int rc = lutldpc_decoder_decode_batch(d, cha, msg0, B, out_bits, out_iters);
+    if (n_dumps) *n_dumps = d->trace.n;
+    d->trace = lutldpc_decoder::Trace();
+    return rc;
 }
 
 int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int B, const double *qb_Cha, int n_qb_Cha,

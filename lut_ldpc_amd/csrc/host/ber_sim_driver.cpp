@@ -315,6 +315,28 @@ void LDPC_BER_Sim_LUT::sim_batch(double snr, int snr_index, int64_t frame0, int 
         }
         cwp = codewords.data();
     }
+    if (decoder_output_verbosity > 1) {
+        // output_verbosity 2 / 3: the message dumps of lut_decode (src/LDPC_Code_LUT.cpp:292-298,311-317,331-337) on top of the
+        // stimuli.  A debug path: the labels of the batch come back to the host (same sampler, same frames), lut_decode_batch
+        // prints the dumps frame after frame (LDPC_Code_LUT::lut_decode_batch_dump), the counters are taken on the host.
+        std::vector<uint8_t> cha((size_t)B * N), msg((size_t)B * N), bits((size_t)B * N);
+        std::vector<int32_t> its((size_t)B);
+        if (lutldpc_decoder_sample_labels(C->device_handle(), &view, seed, (uint32_t)snr_index, (uint64_t)frame0, B, cwp, cha.data(), msg.data()) != LUTLDPC_OK)
+            throw std::runtime_error(std::string("LDPC_BER_Sim_LUT::sim_snr_point(): ") + lutldpc_last_error());
+        const int nzc = C->get_Nq_Cha() / 2;
+        for (int i = 0; i < B; i++) {
+            C->lut_decode_batch(&cha[(size_t)i * N], &msg[(size_t)i * N], 1, &bits[(size_t)i * N], &its[(size_t)i]);     // (prints the dumps)
+            C->print_stimuli(&cha[(size_t)i * N], &bits[(size_t)i * N]);
+            int be = 0, ue = 0;
+            for (int v = 0; v < N; v++) {
+                const int sent = cwp ? cwp[(size_t)i * N + v] : 0;
+                ue += ((cha[(size_t)i * N + v] < nzc) ? 1 : 0) != sent;
+                if (v < K) be += bits[(size_t)i * N + v] != sent;
+            }
+            stats[i] = FrameStats{its[(size_t)i], be ? 1 : 0, be, ue};
+        }
+        return;
+    }
     // output_verbosity > 0: the reference prints every frame's labels and decided bits (src/LDPC_Code_LUT.cpp:228-238)
     std::vector<uint8_t> cha_dump, bits_dump;
     if (decoder_output_verbosity > 0) { cha_dump.resize((size_t)B * N); bits_dump.resize((size_t)B * N); }

@@ -9,6 +9,7 @@
 
 #include <cstring>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 
@@ -146,6 +147,22 @@ lutldpc_decoder *lutldpc_codec_decoder(lutldpc_codec *c) {
 int lutldpc_codec_decode_llr_batch(lutldpc_codec *c, const double *llr, int B, uint8_t *bits, int32_t *iters) {
     return guarded([&] { if (!c || !llr || !bits || !iters) throw std::invalid_argument("NULL argument"); c->C->decode_batch(llr, B, bits, iters); return LUTLDPC_OK; });
 }
+// lut_decode with the message dumps of output_verbosity = level as text (what the reference streams to std::cout); returns the
+// number of bytes the text needs including the terminating NUL (call with buf = NULL first), or a negative error code
+int64_t lutldpc_codec_lut_decode_dump(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, int level, uint8_t *bits, int32_t *iters, char *buf, int64_t cap) {
+    int64_t need = 0;
+    const int rc = guarded([&] {
+        if (!c || !cha || !msg0 || !bits || !iters) throw std::invalid_argument("NULL argument");
+        std::ostringstream os;
+        c->C->lut_decode_batch_dump(cha, msg0, B, bits, iters, level, os);
+        const std::string t = os.str();
+        need = (int64_t)t.size() + 1;
+        if (buf && cap >= need) std::memcpy(buf, t.c_str(), (size_t)need);
+        return LUTLDPC_OK;
+    });
+    return rc == LUTLDPC_OK ? need : rc;
+}
+
 int lutldpc_codec_lut_decode_batch(lutldpc_codec *c, const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters) {
     return guarded([&] { if (!c || !cha || !msg0 || !bits || !iters) throw std::invalid_argument("NULL argument"); c->C->lut_decode_batch(cha, msg0, B, bits, iters); return LUTLDPC_OK; });
 }
@@ -257,6 +274,19 @@ int lutldpc_ber_sim_run(const char *params_path, const char *base_dir, int seed,
 }
 
 int lutldpc_ber_sim_main(int argc, char **argv) { return ber_sim_main(argc, argv); }
+
+// LDPC_BER_Sim_Results::save (src/LDPC_BER_Sim.cpp:342-362) on given numbers: n SNR points with five counters each.  Used by the
+// byte-level known-answer test of the .it writer (the expected bytes are assembled by hand from scripts/itsave.m / itload.m).
+int lutldpc_selftest_write_results_it(const char *path, const double *snr, const int64_t *counters, int n, int nvar, int nchk, double runtime) {
+    return guarded([&] {
+        if (!path || (n > 0 && (!snr || !counters))) throw std::invalid_argument("NULL argument");
+        LDPC_BER_Sim_Results r(nvar, nchk);
+        for (int i = 0; i < n; i++) r.add_snr_point(snr[i], counters[i * 5], counters[i * 5 + 1], counters[i * 5 + 2], counters[i * 5 + 3], counters[i * 5 + 4]);
+        r.save_runtime(runtime);
+        r.write_itfile(path);
+        return LUTLDPC_OK;
+    });
+}
 
 int lutldpc_awgn_llr(uint64_t seed, uint32_t stream, uint64_t frame0, int B, int N, double N0, const uint8_t *codewords, double *llr, int32_t *uncoded) {
     return guarded([&] {

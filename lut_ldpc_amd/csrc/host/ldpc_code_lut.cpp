@@ -378,7 +378,52 @@ lutldpc_decoder *LDPC_Code_LUT::device_handle() {
 }
 
 void LDPC_Code_LUT::lut_decode_batch(const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters) {
+    if (output_verbosity > 1) { lut_decode_batch_dump(cha, msg0, B, bits, iters, output_verbosity > 2 ? 3 : 2, std::cout); return; }
     if (lutldpc_decoder_decode_batch(device_handle(), cha, msg0, B, bits, iters) != LUTLDPC_OK) hip_fail("LDPC_Code_LUT::lut_decode()");
+}
+
+// src/LDPC_Code_LUT.cpp:292-298, 311-317, 331-337: what lut_decode prints with output_verbosity > 1.  The device hands back every
+// dump of every frame (lutldpc_decoder_decode_batch_trace); which of them the reference would have printed for a frame follows
+// from its return code: 0 (passed the test on the channel decisions, :275-279) returns before the first print; a frame that
+// leaves through the exit test of iteration ii (return ii + 1, :327-329) returns BEFORE the dump of that iteration's variable
+// update; everything else prints all of them -- after the last iteration too, where no variable update ran (:331 is outside the
+// `if`).  std::hex / std::uppercase / setfill('0') are sticky in the reference's stream, so the iteration numbers of the
+// headlines come out in upper-case hex.
+void LDPC_Code_LUT::lut_decode_batch_dump(const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters, int level, std::ostream &os) {
+    if (level < 2) level = 2;
+    if (level > 3) level = 3;
+    const int per_iter = level - 1, n_dumps = 1 + max_iters * per_iter;
+    for (int f0 = 0; f0 < B; f0 += 64) {                           // a debug path: 64 frames per device call
+        const int n = std::min(64, B - f0);
+        std::vector<uint8_t> trace((size_t)n_dumps * (size_t)n * (size_t)num_edges);
+        int32_t got = 0;
+        if (lutldpc_decoder_decode_batch_trace(device_handle(), cha + (size_t)f0 * nvar, msg0 + (size_t)f0 * nvar, n, level, bits + (size_t)f0 * nvar, iters + f0,
+                                               trace.data(), (int64_t)trace.size(), &got) != LUTLDPC_OK || got != n_dumps)
+            hip_fail("LDPC_Code_LUT::lut_decode() with output_verbosity > 1");
+        auto row = [&](int dump, int f) { return trace.data() + ((size_t)dump * (size_t)n + (size_t)f) * (size_t)num_edges; };
+        auto print = [&](const uint8_t *m) {
+            for (int e = 0; e < num_edges; e++) os << std::setfill('0') << std::setw(8) << std::uppercase << std::hex << (int)m[e] << "  ";
+            os << std::endl;
+        };
+        for (int f = 0; f < n; f++) {
+            const int rc = iters[f0 + f];
+            if (rc == 0) continue;                                   // :275-279
+            const auto flags = os.flags();
+            const char fill = os.fill();
+            os << "Initial VN-to-CN messages: " << std::endl;
+            print(row(0, f));
+            const int last = rc > 0 && rc < max_iters ? rc - 1 : max_iters - 1;       // last iteration that prints anything
+            const bool early = rc > 0 && rc < max_iters;                             // (rc == max_iters: the final syndrome test, no early return)
+            for (int ii = 0; ii <= last; ii++) {
+                if (level > 2) { os << "CN-to-VN messages after CN update at iteration " << ii << ":" << std::endl; print(row(1 + ii * per_iter, f)); }
+                if (early && ii == last) break;
+                os << "VN-to-CN messages after VN update at iteration " << ii << ":" << std::endl;
+                print(row(1 + ii * per_iter + (per_iter - 1), f));
+            }
+            os.flags(flags);
+            os.fill(fill);
+        }
+    }
 }
 
 void LDPC_Code_LUT::decode_batch(const double *llr, int B, uint8_t *bits, int32_t *iters) {

@@ -9,6 +9,7 @@
 // only builds the index arrays / tables and forwards.  Like the reference object it is not
 // re-entrant (one instance per host thread / stream).
 #pragma once
+#include <ostream>
 #include "ldpc_parity.hpp"
 #include "lut_design.hpp"
 #include "lut_tree.hpp"
@@ -83,6 +84,10 @@ public:
     // llr[B*nvar] -> bits[B*nvar] (all code bits; the systematic part is the first get_ninfo())
     void decode_batch(const double *llr, int B, uint8_t *bits, int32_t *iters);
     void lut_decode_batch(const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters);
+    // the same with the message dumps of output_verbosity = level (2 or 3; src/LDPC_Code_LUT.cpp:292-298,311-317,331-337) written
+    // to `os`, frame after frame, as the reference streams them to std::cout; lut_decode_batch calls it with std::cout when
+    // set_output_verbosity(>= 2) is in force
+    void lut_decode_batch_dump(const uint8_t *cha, const uint8_t *msg0, int B, uint8_t *bits, int32_t *iters, int level, std::ostream &os);
     lutldpc_decoder *device_handle();        // creates the HIP decoder on first use
     void set_device(int device);             // default 0; -1 = host-only (set-up without a GPU)
 

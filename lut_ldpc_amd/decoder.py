@@ -64,6 +64,20 @@ class Decoder:
                                                _p(iters, C.c_int32)))
         return out, iters
 
+    def lut_decode_batch_trace(self, cha, msg0, level, n_edges):
+        """Debug path: (bits, iters, trace uint8 [n_dumps, B, E]) -- the edge messages after the initialisation, (level 3) every
+        check pass and every variable pass, in the print order of output_verbosity = level (src/LDPC_Code_LUT.cpp:292-337)."""
+        cha = np.ascontiguousarray(cha, np.uint8); msg0 = np.ascontiguousarray(msg0, np.uint8)
+        B, N = cha.shape
+        n_dumps = 1 + self.max_iters * (int(level) - 1)
+        out = np.empty((B, N), np.uint8); iters = np.empty(B, np.int32)
+        trace = np.empty((n_dumps, B, int(n_edges)), np.uint8)
+        got = C.c_int32()
+        check(lib.lutldpc_decoder_decode_batch_trace(self._h, _p(cha, C.c_uint8), _p(msg0, C.c_uint8), B, int(level), _p(out, C.c_uint8), _p(iters, C.c_int32),
+                                                     _p(trace, C.c_uint8), trace.size, C.byref(got)))
+        assert got.value == n_dumps
+        return out, iters, trace
+
     def decode_llr_batch(self, llr, qb_cha, qb_msg, mode=0, cha2msg_map=None):
         llr = np.ascontiguousarray(llr, np.float64)
         B, N = llr.shape

@@ -231,6 +231,62 @@ int or_codec_lut_decode(or_codec *c, const int *cha, const int *msg0, unsigned c
     return or_codec_syndrome_ok(c, out) ? c->max_iters : -c->max_iters;
 }
 
+/* lut_decode with output_verbosity = level > 1: the message dumps of LDPC_Code_LUT.cpp:292-298 (initial), :311-317 (after the
+ * check update, level > 2) and :331-337 (after the variable update), appended to the text file `path` exactly as the reference
+ * streams them to std::cout: every message as setfill('0') << setw(8) << uppercase << hex, two blanks after each; std::hex and
+ * std::uppercase are sticky, so the iteration numbers of the later headlines come out in upper-case hex as well.  A frame that
+ * leaves through the exit test returns BEFORE the dump of its last variable update (:327-329 precede :331). */
+static void dump_msgs(FILE *f, const or_codec *c)
+{
+    for (int e = 0; e < c->code->nedges; e++) fprintf(f, "%08X  ", (unsigned)c->msgs[e]);
+    fprintf(f, "\n");
+}
+int or_codec_lut_decode_dump(or_codec *c, const int *cha, const int *msg0, unsigned char *out, int level, const char *path)
+{
+    const or_code *H = c->code;
+    int in[512], res[512];
+    FILE *f = fopen(path, "a");
+    if (!f) return -999999;
+    for (int v = 0; v < c->nvar; v++) out[v] = cha[v] < c->Nq_Cha / 2;
+    if (c->pisc && or_codec_syndrome_ok(c, out)) { fclose(f); return 0; }
+    int e = 0;
+    for (int v = 0; v < c->nvar; v++) for (int k = 0; k < H->dv[v]; k++) c->msgs[e++] = msg0[v];
+    if (level > 1) { fprintf(f, "Initial VN-to-CN messages: \n"); dump_msgs(f, c); }
+    for (int ii = 0; ii < c->max_iters; ii++) {
+        e = 0;
+        for (int cc = 0; cc < c->nchk; cc++) {
+            int dc = H->dc[cc];
+            if (c->minLUT) chk_update_minsum(c, cc, e, ii);
+            else {
+                for (int k = 0; k < dc; k++) in[k] = c->msgs[c->cn_msg_idx[e + k]];
+                or_tree_chk_msg_update(c->chk_trees->t[c->chk_tree_idx_iter[ii]][c->chk_tree_idx_degree[cc]], in, dc, res);
+                for (int k = 0; k < dc; k++) c->msgs[c->cn_msg_idx[e + k]] = res[k];
+            }
+            e += dc;
+        }
+        if (level > 2) { fprintf(f, "CN-to-VN messages after CN update at iteration %X:\n", (unsigned)ii); dump_msgs(f, c); }
+        if (ii != c->max_iters - 1) {
+            e = 0;
+            for (int v = 0; v < c->nvar; v++) {
+                int dv = H->dv[v];
+                or_tree_var_msg_update(c->var_trees->t[c->var_tree_idx_iter[ii]][c->var_tree_idx_degree[v]], c->msgs + e, dv, cha[v], res);
+                for (int k = 0; k < dv; k++) c->msgs[e + k] = res[k];
+                e += dv;
+            }
+            if (c->psc && syndrome_msgs(c, c->Nq_Msg.v[ii + 1], out)) { fclose(f); return ii + 1; }
+        }
+        if (level > 1) { fprintf(f, "VN-to-CN messages after VN update at iteration %X:\n", (unsigned)ii); dump_msgs(f, c); }
+    }
+    e = 0;
+    for (int v = 0; v < c->nvar; v++) {
+        int dv = H->dv[v];
+        out[v] = or_tree_dec_update(c->var_trees->t[c->var_tree_idx_iter[c->max_iters - 1]][c->var_tree_idx_degree[v]], c->msgs + e, dv, cha[v]) < 1;
+        e += dv;
+    }
+    fclose(f);
+    return or_codec_syndrome_ok(c, out) ? c->max_iters : -c->max_iters;
+}
+
 /* decode(const vec&, bvec&), LDPC_Code_LUT.cpp:204-226 (the caller keeps the first
  * nvar - nchk_lin_indep bits as systematic bits) */
 int or_codec_decode_llr(or_codec *c, const double *llr, unsigned char *out, int *cha_labels, int *msg_labels)

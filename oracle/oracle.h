@@ -185,6 +185,8 @@ int       or_codec_set_trees_txt(or_codec *c, const char *var_txt, const char *c
 void      or_codec_set_exit_conditions(or_codec *c, int max_iters, int psc, int pisc); /* :176-185 */
 /* lut_decode, LDPC_Code_LUT.cpp:259-353.  cha/msg0: nvar labels; out: nvar bits (0/1) */
 int       or_codec_lut_decode(or_codec *c, const int *cha, const int *msg0, unsigned char *out);
+/* the same with the message dumps of output_verbosity = level (2 or 3) appended to the text file `path` */
+int       or_codec_lut_decode_dump(or_codec *c, const int *cha, const int *msg0, unsigned char *out, int level, const char *path);
 /* decode(vec llr), LDPC_Code_LUT.cpp:204-239: quantise then lut_decode; returns iteration code */
 int       or_codec_decode_llr(or_codec *c, const double *llr, unsigned char *out,
                               int *cha_labels, int *msg_labels);

@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
             "or_codec_set_trees_txt": (C.c_int, [vp, cp, cp, C.c_int, u8p, C.c_int, ip, C.c_int]),
             "or_codec_set_exit_conditions": (None, [vp, C.c_int, C.c_int, C.c_int]),
             "or_codec_lut_decode_batch_u8": (None, [vp, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int32)]),
+            "or_codec_lut_decode_dump": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u8p, C.c_int, C.c_char_p]),
             "or_codec_decode_llr": (C.c_int, [vp, dp, u8p, ip, ip]),
             "or_sim_awgn_llr": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_double, u8p, dp, ip]),
             "or_bp_new": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -239,6 +240,26 @@ class Codec:
         lib().or_codec_lut_decode_batch_u8(self._h, _u8p(cha), _u8p(msg0), B, _u8p(out),
                                            iters.ctypes.data_as(C.POINTER(C.c_int32)))
         return out, iters
+
+    def lut_decode_dump(self, cha: np.ndarray, msg0: np.ndarray, level: int):
+        """Frame by frame with output_verbosity = level (2 or 3): (bits, iters, the text the reference streams to std::cout,
+        src/LDPC_Code_LUT.cpp:292-298,311-317,331-337)."""
+        import os, tempfile
+        cha = np.ascontiguousarray(cha, np.int32)
+        msg0 = np.ascontiguousarray(msg0, np.int32)
+        B, N = cha.shape
+        out = np.zeros((B, N), np.uint8)
+        iters = np.zeros(B, np.int32)
+        fd, path = tempfile.mkstemp(suffix=".txt")
+        os.close(fd)
+        try:
+            for f in range(B):
+                iters[f] = lib().or_codec_lut_decode_dump(self._h, cha[f].ctypes.data_as(C.POINTER(C.c_int)), msg0[f].ctypes.data_as(C.POINTER(C.c_int)),
+                                                         _u8p(out[f]), int(level), path.encode())
+            text = open(path).read()
+        finally:
+            os.unlink(path)
+        return out, iters, text
 
     def lut_decode_batch_flat(self, cha: np.ndarray, msg0: np.ndarray, threads: int = 0):
         """Flat-table mode (or_flat.c): same results, trees flattened to arrays, one frame per thread (0 = all cores)."""

@@ -117,7 +117,7 @@ def test_c5_wide_checks(name):
     (as shipped) and the 31-leaf CHKTREE (min_lut = false).  700 frames = two frame groups, generated kernels."""
     cd = oracle_codec(name)
     dec = product_decoder(cd)
-    assert dec.describe()["vn_classes"][0]["kernel"] == "lutldpc_jit_pass" and dec.describe()["resident"] == 1, dec.describe()
+    assert dec.describe()["vn_classes"][0]["kernel"] == "lutldpc_jit_pass" and dec.describe()["resident"] == (1 if name == "c5_minlut" else 0), dec.describe()      # (the 31-leaf CHKTREE runs faster through the streaming pass kernels)
     cha, msg, _ = awgn_labels(cd, 700, 4.0, seed=31, mode=1)
     compare(cd, dec, cha, msg, True, True)
     compare(cd, dec, cha, msg, False, False)

@@ -249,3 +249,35 @@ def test_random_irregular_codes(tmp_path, case, resident, monkeypatch):
     _compare(cd, dec, cha, msg, False, False)
     assert len(set(it.tolist())) >= 2
     dec.close()
+
+
+@pytest.mark.parametrize("name,level", [("n500_q4_i8", 2), ("n500_q4_i8", 3), ("reg36_n1000_q3_chklut", 3), ("reg36_n1000_mixed", 2)])
+def test_output_verbosity_message_dumps_match_the_oracle_text(name, level):
+    """output_verbosity 2 / 3 (src/LDPC_Code_LUT.cpp:292-298,311-317,331-337): the initial, check-to-variable (level 3) and
+    variable-to-check messages of every iteration, printed frame after frame -- the golden-vector format SURVEY section 7 names.
+    The product's text (LDPC_Code_LUT::lut_decode with the dumps taken on the device) equals the oracle's restatement of those
+    print statements: frames that pass the test on the channel decisions print nothing, frames that leave through the exit test
+    stop before the dump of their last variable update, iteration numbers in upper-case hex (std::hex is sticky)."""
+    from test_host_design_parity import product_codec
+    cd = oracle_codec(name)
+    pcd = product_codec(name, device=0)
+    assert pcd.var_trees_txt == cd.var_tree_txt                        # same tables on both sides (design parity)
+    cha, msg, _ = awgn_labels(cd, 70, 2.6, seed=level)
+    cha[5] = cd.nq_cha - 1; msg[5] = cd.nq_msg[0] - 1                   # passes the test on the channel decisions
+    for psc, pisc in ((True, True), (False, False)):
+        cd.set_exit_conditions(cd.max_iters, psc, pisc)
+        pcd.set_exit_conditions(cd.max_iters, psc, pisc)
+        wb, wi, wtxt = cd.lut_decode_dump(cha, msg, level)
+        gb, gi, gtxt = pcd.lut_decode_dump(cha, msg, level)
+        assert (wi == gi).all() and (wb == gb).all()
+        if psc:
+            assert (wi == 0).sum() >= 1 and ((wi > 0) & (wi < cd.max_iters)).sum() >= 1      # every kind of return is in the text
+        assert len(wtxt) > 1000 and gtxt == wtxt, (len(gtxt), len(wtxt), next((i for i in range(min(len(gtxt), len(wtxt))) if gtxt[i] != wtxt[i]), None))
+    # the raw trace of the decoder handle: dump 0 = every edge carries its node's initial message (:284-289)
+    dec = product_decoder(cd)
+    dec.set_exit_conditions(cd.max_iters, False, False)
+    _, _, tr = dec.lut_decode_batch_trace(cha[:9], msg[:9], 3, cd.code.nedges)
+    assert tr.shape == (1 + 2 * cd.max_iters, 9, cd.code.nedges)
+    assert (tr[0] == np.repeat(msg[:9], cd.code.dv, axis=1)).all()
+    dec.close()
+    pcd.close()
