@@ -12,6 +12,7 @@
 // decoder, which is the point of the comparison.
 #include "../../../include/lut_ldpc_hip.h"
 #include "../../../include/lut_ldpc_bp.h"
+#include "kernels_common.hpp"      // launch_k: every kernel argument segment <= 128 bytes
 
 #include <hip/hip_runtime.h>
 
@@ -227,18 +228,18 @@ int decode_rows(lutldpc_bp_decoder *d, int B, int Bpad) {
     const unsigned gy = (unsigned)(Bpad / 256);
     const unsigned gxN = (unsigned)std::min(d->nvar, 4096), gxM = (unsigned)std::min(d->nchk, 4096);
     BpParams P{d->d2, d->d3, d->qmax, Bpad};
-    hipLaunchKernelGGL(bp_start_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, B, Bpad, d->max_iters);
-    hipLaunchKernelGGL(bp_init_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_out.p, d->d_mvc.p, d->d_vn_ptr.p, d->nvar, Bpad);
+    lutldpc::launch_k(bp_start_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, B, Bpad, d->max_iters);
+    lutldpc::launch_k(bp_init_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_out.p, d->d_mvc.p, d->d_vn_ptr.p, d->nvar, Bpad);
     if (d->pisc) {
-        hipLaunchKernelGGL(bp_syndrome_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_active.p, d->d_fail.p, d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, Bpad);
-        hipLaunchKernelGGL(bp_state_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, Bpad, 0);
+        lutldpc::launch_k(bp_syndrome_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_active.p, d->d_fail.p, d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, Bpad);
+        lutldpc::launch_k(bp_state_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, Bpad, 0);
     }
     for (int it = 1; it <= d->max_iters; it++) {
-        hipLaunchKernelGGL(bp_cn_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_mvc.p, d->d_mcv.p, d->d_active.p, d->d_cn_ptr.p, d->d_cn_idx.p, d->d_table.p, P, d->nchk);
-        hipLaunchKernelGGL(bp_vn_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_out.p, d->d_mvc.p, d->d_mcv.p, d->d_active.p, d->d_vn_ptr.p, d->nvar, Bpad, d->qmax);
+        lutldpc::launch_k(bp_cn_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_mvc.p, d->d_mcv.p, d->d_active.p, d->d_cn_ptr.p, d->d_cn_idx.p, d->d_table.p, P, d->nchk);
+        lutldpc::launch_k(bp_vn_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_in.p, d->d_out.p, d->d_mvc.p, d->d_mcv.p, d->d_active.p, d->d_vn_ptr.p, d->nvar, Bpad, d->qmax);
         if (d->psc) {
-            hipLaunchKernelGGL(bp_syndrome_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_out.p, d->d_active.p, d->d_fail.p, d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, Bpad);
-            hipLaunchKernelGGL(bp_state_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, Bpad, it);
+            lutldpc::launch_k(bp_syndrome_kernel, dim3(gxM, gy), dim3(256), 0, d->stream, d->d_out.p, d->d_active.p, d->d_fail.p, d->d_cn_ptr.p, d->d_cn_vn.p, d->nchk, Bpad);
+            lutldpc::launch_k(bp_state_kernel, dim3(gy), dim3(256), 0, d->stream, d->d_active.p, d->d_iters.p, d->d_fail.p, Bpad, it);
         }
     }
     const hipError_t e = hipGetLastError();
@@ -262,14 +263,14 @@ int decode_common(lutldpc_bp_decoder *d, const double *llr, const int32_t *q, in
     if (llr) {
         BP_TRY(d->d_llr.alloc(n));
         BP_TRY(hipMemcpyAsync(d->d_llr.p, llr, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(bp_load_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_llr.p, (const int32_t *)nullptr, d->d_in.p, B, d->nvar, Bpad, std::ldexp(1.0, d->d1), d->qmax);
+        lutldpc::launch_k(bp_load_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_llr.p, (const int32_t *)nullptr, d->d_in.p, B, d->nvar, Bpad, std::ldexp(1.0, d->d1), d->qmax);
     } else {
         BP_TRY(d->d_q_in.alloc(n));
         BP_TRY(hipMemcpyAsync(d->d_q_in.p, q, n * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(bp_load_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, (const double *)nullptr, d->d_q_in.p, d->d_in.p, B, d->nvar, Bpad, 1.0, d->qmax);
+        lutldpc::launch_k(bp_load_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, (const double *)nullptr, d->d_q_in.p, d->d_in.p, B, d->nvar, Bpad, 1.0, d->qmax);
     }
     if (int rc = decode_rows(d, B, Bpad)) return rc;
-    hipLaunchKernelGGL(bp_store_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_out.p, d->d_bits.p, out_qllr ? d->d_q_out.p : nullptr, B, d->nvar, Bpad);
+    lutldpc::launch_k(bp_store_kernel, dim3(gxN, gy), dim3(256), 0, d->stream, d->d_out.p, d->d_bits.p, out_qllr ? d->d_q_out.p : nullptr, B, d->nvar, Bpad);
     BP_TRY(hipMemcpyAsync(out_bits, d->d_bits.p, n, hipMemcpyDeviceToHost, d->stream));
     BP_TRY(hipMemcpyAsync(out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, d->stream));
     if (out_qllr) BP_TRY(hipMemcpyAsync(out_qllr, d->d_q_out.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));

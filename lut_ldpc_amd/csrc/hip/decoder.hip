@@ -149,6 +149,16 @@ struct lutldpc_decoder {
     int compact_keep = 1;                                           // LUTLDPC_COMPACT_KEEP: the frames that left keep their rows, bits recovered once at the end
     DevBuf<int32_t> d_frame_of, d_perm, d_tmp3, d_ctl, d_slot_of, d_iters_tmp;
     DevBuf<int32_t> d_grp;                           // per frame group: every frame failed the probe of the test on the channel decisions
+    // Parameter structures of the per-class / generic / sampler kernels live in DEVICE memory (kernel arguments stay <= 128 bytes,
+    // kernels_common.hpp: launch_k): a small arena keyed by content.  The first decode of a shape runs as plain launches and
+    // uploads what it needs; the captured second run finds every structure there already.
+    struct ParamArena {
+        std::map<std::string, size_t> off_of;        // content -> byte offset (the key's bytes are the host copy the upload reads)
+        std::vector<std::unique_ptr<DevBuf<uint8_t>>> chunks;
+        std::vector<size_t> chunk_base;
+        size_t used = 0, cap = 0;
+        void release() { for (auto &c : chunks) c->release(); chunks.clear(); chunk_base.clear(); off_of.clear(); used = cap = 0; }
+    } params;
     // message dumps of output_verbosity >= 2 (src/LDPC_Code_LUT.cpp:292-298,311-317,331-337): a small-batch debug path -- per-class
     // streaming launches, the edge rows copied out after the edge initialisation, (level > 2) every check pass and every
     // variable pass.  host: [dump][B][E] bytes, dumps in the reference's print order.
@@ -728,6 +738,46 @@ int check_batch_buffers(const lutldpc_decoder *d, int Bpad) {
         }                                                                                           \
     } while (0)
 
+// device copy of a parameter structure (see lutldpc_decoder::ParamArena); nullptr + last error on failure
+constexpr size_t kParamChunk = 1u << 20;
+const void *dev_param_bytes(lutldpc_decoder *d, const void *src, size_t n) {
+    auto &A = d->params;
+    std::string key((const char *)src, n);
+    auto it = A.off_of.find(key);
+    size_t off;
+    if (it == A.off_of.end()) {
+        const size_t need = (n + 63) / 64 * 64;
+        if (A.chunks.empty() || A.used + need > A.cap) {
+            if (A.chunks.size() >= 64) {          // 64 MB of distinct parameter blocks: a caller with ever-changing shapes -- start over
+                (void)hipStreamSynchronize(d->stream);
+                d->drop_graphs();
+                A.release();
+            }
+            std::unique_ptr<DevBuf<uint8_t>> c(new DevBuf<uint8_t>());
+            if (c->alloc(std::max(kParamChunk, need)) != hipSuccess) { fail(LUTLDPC_ERR_HIP, "parameter arena: hipMalloc failed"); return nullptr; }
+            A.chunk_base.push_back(A.cap);
+            A.used = A.cap;
+            A.cap += c->n;
+            A.chunks.push_back(std::move(c));
+        }
+        off = A.used;
+        A.used += need;
+        it = A.off_of.emplace(std::move(key), off).first;
+        const size_t ci = A.chunks.size() - 1;
+        if (hipMemcpyAsync(A.chunks[ci]->p + (off - A.chunk_base[ci]), it->first.data(), n, hipMemcpyHostToDevice, d->stream) != hipSuccess) {
+            fail(LUTLDPC_ERR_HIP, "parameter arena: upload failed");
+            return nullptr;
+        }
+    } else off = it->second;
+    size_t ci = A.chunks.size() - 1;
+    while (ci > 0 && A.chunk_base[ci] > off) ci--;
+    return A.chunks[ci]->p + (off - A.chunk_base[ci]);
+}
+template <class T> const T *dev_param(lutldpc_decoder *d, const T &v) { return static_cast<const T *>(dev_param_bytes(d, &v, sizeof(T))); }
+#define DEV_PARAM(var, d, v)                      \
+    const auto *var = dev_param((d), (v));        \
+    if (!var) return LUTLDPC_ERR_HIP
+
 // instantiate a launch for the decoder's packing
 #define PACK_DISPATCH(d, ...)                        \
     do {                                             \
@@ -742,7 +792,7 @@ int launch_state(lutldpc_decoder *d, int B, int Bpad, int mode, int value, int f
     if (f1 < 0) f1 = Bpad;
     if (f1 <= f0) return LUTLDPC_OK;
     if (mode == 0) HIP_TRY(hipMemsetAsync(d->d_vfail.p + (size_t)kVfailSlots * d->Bcap, 0, (size_t)kVfailSlots * d->Bcap, d->stream));
-    hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)((f1 - f0) / 256)), dim3(256), 0, d->stream,
+    launch_k(frame_state_kernel, dim3((unsigned)((f1 - f0) / 256)), dim3(256), 0, d->stream,
                        d->d_state.p, d->d_vfail.p + (size_t)sel * kVfailSlots * d->Bcap, d->d_iters.p, B, f0, f1, mode, value, d->Bcap);
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -752,7 +802,7 @@ int launch_syndrome(lutldpc_decoder *d, int G, int sel = 0) {
     Timed t(d, LUTLDPC_K_SYNDROME);
     const int cpw = 8;
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
-    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+    PACK_DISPATCH(d, launch_k(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                        reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p + (size_t)sel * kVfailSlots * d->Bcap),
                        d->d_cn_ptr.p, reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, cpw, d->Bcap / 4, -1, (const int32_t *)nullptr, (int32_t *)nullptr));
     LAUNCH_CHECK();
@@ -767,9 +817,9 @@ int launch_syndrome_of_labels(lutldpc_decoder *d, int G) {
     HIP_TRY(hipMemsetAsync(d->d_grp.p, 0, sizeof(int32_t) * (size_t)G, d->stream));
 #define SYN_ARGS(CPW, SKIP, OUT) d->d_cha_t.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_cn_ptr.p, \
                      reinterpret_cast<const uint32_t *>(d->d_cn_vn.p), d->nchk, d->nvar, CPW, d->Bcap / 4, sbit, SKIP, OUT
-    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(1u, (unsigned)G), dim3(64), 0, d->stream, SYN_ARGS(64, (const int32_t *)nullptr, d->d_grp.p)));
+    PACK_DISPATCH(d, launch_k(syndrome_bits_kernel<PK>, dim3(1u, (unsigned)G), dim3(64), 0, d->stream, SYN_ARGS(64, (const int32_t *)nullptr, d->d_grp.p)));
     unsigned bx = (unsigned)((d->nchk + 4 * cpw - 1) / (4 * cpw));
-    PACK_DISPATCH(d, hipLaunchKernelGGL(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, SYN_ARGS(cpw, (const int32_t *)d->d_grp.p, (int32_t *)nullptr)));
+    PACK_DISPATCH(d, launch_k(syndrome_bits_kernel<PK>, dim3(bx, (unsigned)G), dim3(256), 0, d->stream, SYN_ARGS(cpw, (const int32_t *)d->d_grp.p, (int32_t *)nullptr)));
 #undef SYN_ARGS
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -779,18 +829,18 @@ int launch_syndrome_of_labels(lutldpc_decoder *d, int G) {
 int launch_transpose_in(lutldpc_decoder *d, const uint8_t *src, uint8_t *dst_rows, int B, int G, int limit) {
     const int N = d->nvar;
     if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0)
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
+        PACK_DISPATCH(d, launch_k(transpose_in_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
     else
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_in_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
+        PACK_DISPATCH(d, launch_k(transpose_in_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src, dst_rows, B, N, limit));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
 int launch_transpose_out(lutldpc_decoder *d, const uint8_t *src_rows, uint8_t *dst, int B, int G, int rows = 0) {
     const int N = rows > 0 ? rows : d->nvar;
     if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
+        PACK_DISPATCH(d, launch_k(transpose_out_vec_kernel<PK>, dim3((unsigned)((N + 127) / 128), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
     else
-        PACK_DISPATCH(d, hipLaunchKernelGGL(transpose_out_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
+        PACK_DISPATCH(d, launch_k(transpose_out_kernel<PK>, dim3((unsigned)((N + 31) / 32), (unsigned)G), dim3(256), 0, d->stream, src_rows, dst, B, N));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
 }
@@ -824,9 +874,11 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
         for (int i = 0; i < P.n_seg; i++) {
             if (!(*fast)[(size_t)i].ok) continue;
             bool ok = false;
-            PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, (*fast)[(size_t)i].P, G, nz, check, write_hard, d->npw_vn((*fast)[(size_t)i].P.deg), d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
-                                     reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p,
-                                     d->d_fast_idx.p, d->E, d->nvar, d->Bcap / 4));
+            FastParams FP = (*fast)[(size_t)i].P;
+            fill_vn_fast(FP, G, nz, check, write_hard, d->npw_vn(FP.deg), d->E, d->nvar, d->Bcap / 4);
+            DEV_PARAM(dFP, d, FP);
+            PACK_DISPATCH(d, ok = launch_vn_fast<KIND, PK>(d->stream, FP, dFP, d->d_msgs.p, d->d_cha_t.p, d->d_hard.p,
+                                     reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_tables.p, d->d_fast_idx.p));
             if (ok) keep[(size_t)i] = 0;
         }
     // run-time generated kernels (jit.hpp) for the classes without a compile-time one
@@ -845,7 +897,8 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
             const uint32_t *state_w = reinterpret_cast<const uint32_t *>(d->d_state.p);
             uint32_t *vfail_w = reinterpret_cast<uint32_t *>(d->d_vfail.p);
             const int32_t *fidx = d->d_fast_idx.p;
-            void *args[] = {&F, &msgs, &cha, &hard, &state_w, &vfail_w, &tables, &fidx};
+            DEV_PARAM(dF, d, F);
+            void *args[] = {&dF, &msgs, &cha, &hard, &state_w, &vfail_w, &tables, &fidx};
             const unsigned blocks = (unsigned)((F.waves_per_group * G + 3) / 4);
             HIP_TRY(hipModuleLaunchKernel(k->fn, blocks, 1, 1, 256, 1, 1, 0, d->stream, args, nullptr));
             keep[(size_t)i] = 0;
@@ -853,15 +906,16 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
     for (char k : keep) any = any || k;
     if (any) {
         P = filter_params(P, keep);
+        DEV_PARAM(dP, d, P);
         dim3 grid((unsigned)(P.blocks_per_group * G)), block(64);
         const int32_t *list = KIND == TT_CHK ? d->d_cn_list.p : d->d_vn_list.p;
         const int32_t *ptr = KIND == TT_CHK ? d->d_cn_ptr.p : d->d_vn_ptr.p;
         if (plan.lds_tab)
-            PACK_DISPATCH(d, hipLaunchKernelGGL((tree_pass_kernel<KIND, true, PK>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+            PACK_DISPATCH(d, launch_k(tree_pass_kernel<KIND, true, PK>, grid, block, (size_t)plan.lds_bytes, d->stream, dP, d->d_msgs.p, d->d_cha_t.p,
                                d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
                                d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p, plan.out_slots));
         else
-            PACK_DISPATCH(d, hipLaunchKernelGGL((tree_pass_kernel<KIND, false, PK>), grid, block, (size_t)plan.lds_bytes, d->stream, P, d->d_msgs.p, d->d_cha_t.p,
+            PACK_DISPATCH(d, launch_k(tree_pass_kernel<KIND, false, PK>, grid, block, (size_t)plan.lds_bytes, d->stream, dP, d->d_msgs.p, d->d_cha_t.p,
                                d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
                                d->d_ops.p, d->d_tables.p, list, ptr, d->d_cn_idx.p, plan.out_slots));
     }
@@ -878,14 +932,18 @@ int launch_cn_minsum(lutldpc_decoder *d, int G, int nz, int check) {
     if (d->use_fast)
         for (int i = 0; i < P.n_seg; i++) {
             bool ok = false;
-            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->npw_cn(P.seg[i].deg), d->d_msgs.p,
-                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p, d->Bcap / 4));
+            FastParams FP;
+            if (!fill_cn_fast(FP, P.seg[i].deg, P.seg[i].n_nodes, d->cn_idx_off[(size_t)i], G, d->E, nz, check, d->npw_cn(P.seg[i].deg), d->Bcap / 4)) continue;
+            DEV_PARAM(dFP, d, FP);
+            PACK_DISPATCH(d, ok = launch_cn_fast<PK>(d->stream, FP, dFP, d->d_msgs.p,
+                               reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p), d->d_fast_idx.p));
             if (ok) keep[(size_t)i] = 0;
         }
     for (char k : keep) any = any || k;
     if (any) {
         P = filter_params(P, keep);
-        PACK_DISPATCH(d, hipLaunchKernelGGL(cn_minsum_generic_kernel<PK>, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, P, d->d_msgs.p,
+        DEV_PARAM(dP, d, P);
+        PACK_DISPATCH(d, launch_k(cn_minsum_generic_kernel<PK>, dim3((unsigned)(P.blocks_per_group * G)), dim3(64), 0, d->stream, dP, d->d_msgs.p,
                            reinterpret_cast<const uint32_t *>(d->d_state.p), reinterpret_cast<uint32_t *>(d->d_vfail.p),
                            d->d_cn_list.p, d->d_cn_ptr.p, d->d_cn_idx.p));
     }
@@ -1098,14 +1156,14 @@ int launch_late_hard(lutldpc_decoder *d, bool skewed, int g0, int G, const int32
     bool chain_skip = false;
     if (!late_hard_active(d, skewed, &chain_skip) || G <= 0) return LUTLDPC_OK;
     const unsigned gx = ctl ? 1024u : 2048u;
-    PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(gx, (unsigned)((d->nvar + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
+    PACK_DISPATCH(d, launch_k(hard_from_frozen_kernel<PK>, dim3(std::min<unsigned>(gx, (unsigned)((d->nvar + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_msgs.p, d->d_hard.p,
                                         reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_vn_ptr.p, chain_skip ? d->d_chain_internal.p : nullptr, d->nvar, d->E,
                                         d->Nq_Msg[0] / 2, g0, ctl));
     if (chain_skip)
         for (size_t i = 0; i < d->cclass.size(); i++) {
             if (d->chain_idx_off[i] < 0) continue;
             const int n = (int)d->cclass[i].nodes.size(), npw = d->npw_cn_class(i), runs = (n + npw - 1) / npw;
-            PACK_DISPATCH(d, hipLaunchKernelGGL(chain_hard_kernel<PK>, dim3(std::min<unsigned>(512u, (unsigned)((runs + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+            PACK_DISPATCH(d, launch_k(chain_hard_kernel<PK>, dim3(std::min<unsigned>(512u, (unsigned)((runs + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                                                 reinterpret_cast<const uint32_t *>(d->d_state.p), d->d_fast_idx.p + d->cn_idx_off[i], d->d_fast_idx.p + d->chain_idx_off[i],
                                                 d->d_edge_vn.p, n, d->cclass[i].deg, npw, d->nvar, g0, ctl));
         }
@@ -1137,16 +1195,16 @@ int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
     // at the end of the decode like without compaction; otherwise (LUTLDPC_COMPACT_KEEP=0) they are recovered at the check point
     // and the rows dropped
     const bool keep = late && d->compact_keep;
-    hipLaunchKernelGGL(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
+    launch_k(compact_decide_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, s0, n, T, ctl, d->max_iters - 1 - ii, d->compact_margin,
                        d->compact_margin > 0 ? d->compact_min_share : 0.0f, keep ? 1 : 0);
     // (not keep) the decided bits of the frames that left since the last permutation, before their messages are dropped
     if (!keep) if (int rc = launch_late_hard(d, true, h.g0, h.G, ctl)) return rc;
-    hipLaunchKernelGGL(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
+    launch_k(compact_apply_kernel, dim3(1), dim3(1024), 0, d->stream, d->d_state.p, d->d_iters.p, d->d_frame_of.p, pending, d->Bcap, s0, n,
                        d->d_perm.p, d->d_tmp3.p + (size_t)3 * s0, ctl, (late && !keep) ? 1 : 0);
     // (the grid is fixed and small: an empty check point must cost microseconds)
     auto rows = [&](uint8_t *a, int na, uint8_t *b, int nb, int gather) {
         const unsigned blocks = std::min<unsigned>(kPermuteBlocks, (unsigned)((na + nb + kPermuteRows - 1) / kPermuteRows));
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(blocks), dim3(1024), kPermuteLdsBytes, d->stream, a, na, b, nb, h.g0, h.G,
+        PACK_DISPATCH(d, launch_k(permute_rows_kernel<PK>, dim3(blocks), dim3(1024), kPermuteLdsBytes, d->stream, a, na, b, nb, h.g0, h.G,
                                             d->d_perm.p, d->d_ctl.p + 4 * hf, gather));
     };
     rows(d->d_msgs.p, d->E, d->d_cha_t.p, d->nvar, keep ? 2 : 1);
@@ -1157,14 +1215,14 @@ int launch_compaction(lutldpc_decoder *d, HalfRange h, int hf, int ii) {
 // end of the decode: decided bits and iteration codes back into the caller's frame order
 int launch_uncompaction(lutldpc_decoder *d, const HalfRange (&half)[2], int Bpad) {
     Timed t(d, LUTLDPC_K_LAYOUT);
-    hipLaunchKernelGGL(invert_map_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, d->d_slot_of.p, 0, Bpad);
+    launch_k(invert_map_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, d->d_slot_of.p, 0, Bpad);
     for (int hf = 0; hf < 2; hf++) {
         if (half[hf].G <= 0) continue;
-        PACK_DISPATCH(d, hipLaunchKernelGGL(permute_rows_kernel<PK>, dim3(std::min<unsigned>(kPermuteBlocks, (unsigned)((d->nvar + kPermuteRows - 1) / kPermuteRows))), dim3(1024),
+        PACK_DISPATCH(d, launch_k(permute_rows_kernel<PK>, dim3(std::min<unsigned>(kPermuteBlocks, (unsigned)((d->nvar + kPermuteRows - 1) / kPermuteRows))), dim3(1024),
                                             kPermuteLdsBytes, d->stream, d->d_hard.p, d->nvar, (uint8_t *)nullptr, 0,
                                             half[hf].g0, half[hf].G, d->d_slot_of.p, (const int32_t *)nullptr, 0));
     }
-    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_iters.p, d->d_slot_of.p, d->d_iters_tmp.p, 0, Bpad);
+    launch_k(gather_i32_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_iters.p, d->d_slot_of.p, d->d_iters_tmp.p, 0, Bpad);
     HIP_TRY(hipMemcpyAsync(d->d_iters.p, d->d_iters_tmp.p, sizeof(int32_t) * (size_t)Bpad, hipMemcpyDeviceToDevice, d->stream));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -1229,7 +1287,7 @@ int iterate_skewed(lutldpc_decoder *d, int B, int Bpad, int G) {
     const int every = d->compact_every > 0 ? d->compact_every : 2;
     if (compact) {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        hipLaunchKernelGGL(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
+        launch_k(compact_init_kernel, dim3((unsigned)((Bpad + 255) / 256)), dim3(256), 0, d->stream, d->d_frame_of.p, Bpad, d->d_ctl.p, half[0].G, half[1].G);
         LAUNCH_CHECK();
     }
     for (const auto &sl : plan.slots) {
@@ -1405,7 +1463,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
             {
                 Timed t(d, LUTLDPC_K_LAYOUT);
                 const size_t n_words = (size_t)G * (size_t)N * kRowBytes / 4;
-                PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_kernel<PK>, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, n_words, d->Nq_Cha / 2));
+                PACK_DISPATCH(d, launch_k(hard_from_labels_kernel<PK>, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, d->stream, d->d_cha_t.p, d->d_hard.p, n_words, d->Nq_Cha / 2));
                 LAUNCH_CHECK();
             }
             if ((rc = launch_syndrome(d, G))) return rc;
@@ -1413,7 +1471,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         if ((rc = launch_state(d, B, Bpad, 1, 0))) return rc;
         {   // decided bits of the frames that passed = signs of their channel labels (:275); groups without such a frame return at once
             Timed t(d, LUTLDPC_K_LAYOUT);
-            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
+            PACK_DISPATCH(d, launch_k(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
                                                 d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), N, d->Nq_Cha / 2, 0));
             LAUNCH_CHECK();
         }
@@ -1421,7 +1479,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     const bool skewed = d->skew && d->skew_ok && !tracing;      // (a single frame group runs the same launches with an empty second half)
     if (!(skewed && d->first_from_nodes)) {   // :284-289 (the fused pipeline's first check pass reads the initial-message rows itself)
         Timed t(d, LUTLDPC_K_LAYOUT);
-        hipLaunchKernelGGL(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
+        launch_k(init_edges_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)G), dim3(256), 0, d->stream, d->d_msg0_t.p, d->d_msgs.p, d->d_vn_ptr.p, N, E);
         LAUNCH_CHECK();
     }
     if (tracing && (rc = trace_dump(d))) return rc;                              // :292-298
@@ -1449,7 +1507,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         if (skewed && d->psc && d->pisc && compaction_on(d, G) && late_hard_active(d, true, nullptr) && d->compact_keep) {
             // frames that passed the test on the channel decisions may have been moved by a permutation: their decided-bit rows
             // did not travel (no other decided bit exists during the iterations), their channel rows did -- write the bits again
-            PACK_DISPATCH(d, hipLaunchKernelGGL(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
+            PACK_DISPATCH(d, launch_k(hard_from_labels_masked_kernel<PK>, dim3(std::min<unsigned>(1024u, (unsigned)((N + 3) / 4)), (unsigned)G), dim3(256), 0, d->stream,
                                                 d->d_cha_t.p, d->d_hard.p, reinterpret_cast<const uint32_t *>(d->d_state.p), N, d->Nq_Cha / 2, 0));
             LAUNCH_CHECK();
         }
@@ -1558,7 +1616,8 @@ int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint3
     Timed t(d, LUTLDPC_K_FRONTEND);
     const int ppt = 8, npairs = (N + 1) / 2;
     dim3 grid((unsigned)((npairs + 4 * ppt - 1) / (4 * ppt)), (unsigned)G);
-    PACK_DISPATCH(d, hipLaunchKernelGGL(sample_labels_kernel<PK>, grid, dim3(256), 0, d->stream, C, (uint32_t)seed, (uint32_t)(seed >> 32), stream, frame0, B, N, cw,
+    DEV_PARAM(dC, d, C);
+    PACK_DISPATCH(d, launch_k(sample_labels_kernel<PK>, grid, dim3(256), 0, d->stream, dC, (uint32_t)seed, (uint32_t)(seed >> 32), stream, frame0, B, N, cw,
                        d->d_cha_t.p, d->d_msg0_t.p, d->d_stats.p, ppt));
     LAUNCH_CHECK();
     return LUTLDPC_OK;
@@ -1716,6 +1775,7 @@ int lutldpc_decoder_destroy(lutldpc_decoder *d) {
         d->drop_graphs();
         d->d_frame_of.release(); d->d_perm.release(); d->d_tmp3.release(); d->d_ctl.release(); d->d_slot_of.release(); d->d_iters_tmp.release(); d->d_grp.release();
         d->drop_plans();
+        d->params.release();
         d->d_out_iters.release(); d->d_trace.release(); d->d_llr.release(); d->d_qb_cha.release(); d->d_qb_msg.release(); d->d_map.release(); d->d_codewords.release(); d->d_stats.release();
         if (d->stream) (void)hipStreamDestroy(d->stream);
     }
@@ -1792,7 +1852,7 @@ int lutldpc_decoder_decode_llr_batch(lutldpc_decoder *d, const double *llr, int 
     HIP_TRY(hipMemcpyAsync(d->d_qb_cha.p, qb_Cha, sizeof(double) * (size_t)n_qb_Cha, hipMemcpyHostToDevice, d->stream));
     if (mode == 0) HIP_TRY(hipMemcpyAsync(d->d_qb_msg.p, qb_Msg, sizeof(double) * (size_t)n_qb_Msg, hipMemcpyHostToDevice, d->stream));
     else HIP_TRY(hipMemcpyAsync(d->d_map.p, map, sizeof(int32_t) * (size_t)d->Nq_Cha, hipMemcpyHostToDevice, d->stream));
-    hipLaunchKernelGGL(quantize_llr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->d_llr.p, n, d->d_qb_cha.p, n_qb_Cha,
+    launch_k(quantize_llr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->d_llr.p, n, d->d_qb_cha.p, n_qb_Cha,
                        d->d_qb_msg.p, n_qb_Msg, mode, d->d_map.p, d->d_in_cha.p, d->d_in_msg.p);
     LAUNCH_CHECK();
     int rc = decode_device(d, d->d_in_cha.p, d->d_in_msg.p, B, d->d_out_bits.p, d->d_out_iters.p);
@@ -1818,7 +1878,7 @@ int lutldpc_decoder_sim_batch(lutldpc_decoder *d, const lutldpc_channel_cells *c
         Timed t(d, LUTLDPC_K_FRONTEND);
         const int Bpad = d->bpad(B), G = Bpad / d->tile(), rpw = 64;
         const int rows = K_info > 0 ? K_info : 1;
-        PACK_DISPATCH(d, hipLaunchKernelGGL(count_errors_kernel<PK>, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
+        PACK_DISPATCH(d, launch_k(count_errors_kernel<PK>, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)), (unsigned)G), dim3(256), 0, d->stream, d->d_hard.p,
                            codewords ? d->d_codewords.p : nullptr, B, d->nvar, K_info, d->d_iters.p, d->d_stats.p, rpw));
         LAUNCH_CHECK();
     }

@@ -53,9 +53,9 @@ inline bool jit_vn_source(const Program &prog, int kind, int deg, int pack, int 
     const int tab_pad = (tab_bytes + 15) / 16 * 16;
     std::ostringstream o;
     o << kCommonHeaderText << "\nusing namespace lutldpc;\n"
-      << "extern \"C\" __global__ __launch_bounds__(256) void lutldpc_jit_pass(FastParams P, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,\n"
+      << "extern \"C\" __global__ __launch_bounds__(256) void lutldpc_jit_pass(const FastParams *__restrict__ Pp, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,\n"
       << "    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)\n{\n"
-      << "    constexpr int PACK = " << pack << ", DV = " << deg << ", F = 4 * PACK, BITS = " << bits << ";\n";
+      << "    const FastParams &P = *Pp;\n    constexpr int PACK = " << pack << ", DV = " << deg << ", F = 4 * PACK, BITS = " << bits << ";\n";
     if (in_lds) {
         o << "    __shared__ __attribute__((aligned(16))) uint8_t tab[" << tab_pad << "];\n"
           << "    {\n        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[0]);\n"
@@ -187,9 +187,9 @@ inline bool jit_cn_source(const Program &prog, int deg, int pack, int tab_bytes,
     const bool pipe = deg <= 16;
     std::ostringstream o;
     o << kCommonHeaderText << "\nusing namespace lutldpc;\n"
-      << "extern \"C\" __global__ __launch_bounds__(256) void lutldpc_jit_pass(FastParams P, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,\n"
+      << "extern \"C\" __global__ __launch_bounds__(256) void lutldpc_jit_pass(const FastParams *__restrict__ Pp, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,\n"
       << "    const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables, const int32_t *__restrict__ fast_idx)\n{\n"
-      << "    constexpr int PACK = " << pack << ", DEG = " << deg << ", F = 4 * PACK, BITS = " << bits << ";\n    (void)cha; (void)hard;\n";
+      << "    const FastParams &P = *Pp;\n    constexpr int PACK = " << pack << ", DEG = " << deg << ", F = 4 * PACK, BITS = " << bits << ";\n    (void)cha; (void)hard;\n";
     if (in_lds) {
         o << "    __shared__ __attribute__((aligned(16))) uint8_t tab[" << tab_pad << "];\n"
           << "    {\n        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + P.tab_off[0]);\n"

@@ -222,6 +222,19 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t x, int s, uint32_t y) {
     return r;
 }
 
+#ifndef __HIPCC_RTC__
+// Every kernel of the library is launched through this wrapper: its argument segment stays within 128 bytes -- pointers and a few
+// integers; anything larger (role lists, class parameters, channel cells) lives in DEVICE memory and is passed by pointer.  The one
+// device fault this library has shown pointed at the stale tail of a 3472-byte by-value argument segment;
+// the static_assert keeps such a segment from coming back.
+constexpr size_t kMaxKernelArgBytes = 128;
+template <typename... KArgs, typename... Args>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream, Args &&...args) {
+    static_assert((((sizeof(KArgs) + 7) / 8 * 8) + ... + 0) <= kMaxKernelArgBytes, "kernel argument segment above 128 bytes: pass the structure through device memory");
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, static_cast<KArgs>(args)...);
+}
+#endif
+
 // locate the degree class of a block: linear scan over <= kMaxSeg scalar entries
 __device__ __forceinline__ int find_seg(const PassParams &P, int b) {
     int s = 0;

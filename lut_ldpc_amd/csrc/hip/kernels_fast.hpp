@@ -256,9 +256,10 @@ __device__ __forceinline__ void cn_minsum_body(
 
 template <int DEG, int UNR, int PACK>
 __global__ __launch_bounds__(256) void cn_minsum_fast_kernel(
-    FastParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+    const FastParams *__restrict__ Pp, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx)
 {
+    const FastParams &P = *Pp;           // (class parameters in device memory: read with scalar loads as they are needed)
     cn_minsum_body<DEG, UNR, PACK, false>(P, (int)blockIdx.x, msgs, state_w, vfail_w, fast_idx);
 }
 
@@ -503,12 +504,13 @@ __device__ __forceinline__ void vn_balanced_body(
 
 template <int DV, int KIND, bool CHECK, int PACK>
 __global__ __launch_bounds__(256) void vn_balanced_fast_kernel(
-    FastParams P, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
+    const FastParams *__restrict__ Pp, uint8_t *msgs, const uint8_t *cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const uint8_t *__restrict__ tables,
     const int32_t *__restrict__ fast_idx)
 {
     constexpr int NT = (KIND == TT_DEC ? DV : DV - 1) > 1 ? (KIND == TT_DEC ? DV : DV - 1) : 1;   // LUT nodes incl. root
     __shared__ __attribute__((aligned(16))) uint8_t lds_tab[NT * kFastTableStride];
+    const FastParams &P = *Pp;
     vn_balanced_body<DV, KIND, CHECK, PACK>(P, (int)blockIdx.x, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
 
@@ -702,59 +704,63 @@ constexpr int kFastMaxDeg = 20;      // variable / decision nodes
 constexpr int kFastMaxCnDeg = 32;    // check nodes
 
 template <int KIND, bool CHECK, int PACK, int DV>
-void launch_vn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
+void launch_vn_fast_one(hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint8_t *cha, uint8_t *hard, const uint32_t *state_w,
                         uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     const int waves = P.waves_per_group * P.G;
-    hipLaunchKernelGGL((vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, cha, hard, state_w, vfail_w,
-                       tables, fast_idx);
+    launch_k(vn_balanced_fast_kernel<DV, KIND, CHECK, PACK>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, dP, msgs, cha, hard, state_w, vfail_w,
+             tables, fast_idx);
 }
 
 template <int KIND, bool CHECK, int PACK, int... DVs>
-bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint8_t *cha,
+bool dispatch_vn_fast(int deg, std::integer_sequence<int, DVs...>, hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint8_t *cha,
                       uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     bool done = false;
-    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), done = true) : false), ...);
+    ((deg == DVs + 1 ? (launch_vn_fast_one<KIND, CHECK, PACK, DVs + 1>(s, P, dP, msgs, cha, hard, state_w, vfail_w, tables, fast_idx), done = true) : false), ...);
     return done;
 }
 
-// launch one class; returns false when the degree has no instantiation
-template <int KIND, int PACK>
-bool launch_vn_fast(hipStream_t s, FastParams P, int G, int nz, int check, int write_hard, int nodes_per_wave, uint8_t *msgs, const uint8_t *cha,
-                    uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, int E, int N, int vfail_stride_w) {
+// launch one class; returns false when the degree has no instantiation.  P is complete (fill_vn_fast), dP its copy in device memory.
+inline void fill_vn_fast(FastParams &P, int G, int nz, int check, int write_hard, int nodes_per_wave, int E, int N, int vfail_stride_w) {
     P.vfail_stride_w = vfail_stride_w;
     P.G = G; P.E = E; P.N = N; P.nz = nz; P.check = check; P.write_hard = write_hard;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (P.n_nodes + nodes_per_wave - 1) / nodes_per_wave;
+}
+template <int KIND, int PACK>
+bool launch_vn_fast(hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint8_t *cha,
+                    uint8_t *hard, const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx) {
     constexpr auto seq = std::make_integer_sequence<int, kFastMaxDeg>{};
-    if (KIND == TT_VAR && check) return dispatch_vn_fast<KIND, true, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
-    return dispatch_vn_fast<KIND, false, PACK>(P.deg, seq, s, P, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+    if (KIND == TT_VAR && P.check) return dispatch_vn_fast<KIND, true, PACK>(P.deg, seq, s, P, dP, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
+    return dispatch_vn_fast<KIND, false, PACK>(P.deg, seq, s, P, dP, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
 }
 
 template <int PACK, int DEG>
-void launch_cn_fast_one(hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+void launch_cn_fast_one(hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
     // checks evaluated per pipeline step: more = more loads outstanding per wave, fewer = fewer VGPRs = more waves
     constexpr int UNR = DEG <= 4 ? 4 : DEG <= 10 ? 2 : 1;
     const int waves = P.waves_per_group * P.G;
-    hipLaunchKernelGGL((cn_minsum_fast_kernel<DEG, UNR, PACK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P, msgs, state_w, vfail_w, fast_idx);
+    launch_k(cn_minsum_fast_kernel<DEG, UNR, PACK>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, dP, msgs, state_w, vfail_w, fast_idx);
 }
 template <int PACK, int... Ds>
-bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, uint8_t *msgs, const uint32_t *state_w,
+bool dispatch_cn_fast(int deg, std::integer_sequence<int, Ds...>, hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint32_t *state_w,
                       uint32_t *vfail_w, const int32_t *fast_idx) {
     bool done = false;
-    ((deg == Ds + 1 ? (launch_cn_fast_one<PACK, Ds + 1>(s, P, msgs, state_w, vfail_w, fast_idx), done = true) : false), ...);
+    ((deg == Ds + 1 ? (launch_cn_fast_one<PACK, Ds + 1>(s, P, dP, msgs, state_w, vfail_w, fast_idx), done = true) : false), ...);
     return done;
 }
 
-// min-sum: one launch per degree class
-template <int PACK>
-bool launch_cn_fast(hipStream_t s, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, uint8_t *msgs,
-                    const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx, int vfail_stride_w) {
+// min-sum: one launch per degree class (P from fill_cn_fast, dP its copy in device memory)
+inline bool fill_cn_fast(FastParams &P, int deg, int n_nodes, int idx_off, int G, int E, int nz, int check, int nodes_per_wave, int vfail_stride_w) {
     if (!is_pow2(nz) || nz > 64 || deg < 2 || deg > kFastMaxCnDeg) return false;
-    FastParams P{};
+    P = FastParams{};
     P.n_nodes = n_nodes; P.idx_off = idx_off; P.G = G; P.E = E; P.nz = nz; P.check = check; P.deg = deg; P.vfail_stride_w = vfail_stride_w;
     P.nodes_per_wave = nodes_per_wave;
     P.waves_per_group = (n_nodes + nodes_per_wave - 1) / nodes_per_wave;
-    return dispatch_cn_fast<PACK>(deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, msgs, state_w, vfail_w, fast_idx);
+    return true;
+}
+template <int PACK>
+bool launch_cn_fast(hipStream_t s, const FastParams &P, const FastParams *dP, uint8_t *msgs, const uint32_t *state_w, uint32_t *vfail_w, const int32_t *fast_idx) {
+    return dispatch_cn_fast<PACK>(P.deg, std::make_integer_sequence<int, kFastMaxCnDeg>{}, s, P, dP, msgs, state_w, vfail_w, fast_idx);
 }
 
 // code-object preload of the per-class translation units (see preload_fused)
@@ -774,11 +780,11 @@ template <int PACK, int BUCKET>
 void launch_fused(hipStream_t s, const RoleParams *d_roles, const int32_t *items, int n_blocks, int prio, bool vn_check, uint8_t *msgs, const uint8_t *cha, uint8_t *hard,
                   const uint32_t *state_w, uint32_t *vfail_w, const uint8_t *tables, const int32_t *fast_idx, const uint8_t *msg0) {
     if (vn_check)
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, true, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx, msg0);
+        launch_k(pass_fused_kernel<PACK, true, BUCKET>, dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
+                 state_w, vfail_w, tables, fast_idx, msg0);
     else
-        hipLaunchKernelGGL((pass_fused_kernel<PACK, false, BUCKET>), dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
-                           state_w, vfail_w, tables, fast_idx, msg0);
+        launch_k(pass_fused_kernel<PACK, false, BUCKET>, dim3((unsigned)n_blocks), dim3(256), 0, s, d_roles, reinterpret_cast<const int2 *>(items), prio, msgs, cha, hard,
+                 state_w, vfail_w, tables, fast_idx, msg0);
 }
 // force the code object of this translation unit onto the current device now (HIP loads code objects lazily, at the first
 // launch of one of their kernels): decoder.hip calls these at decoder creation, see preload_code_objects
@@ -790,12 +796,12 @@ hipError_t preload_fused() {
 
 #define LUTLDPC_FUSED_SIG (hipStream_t, const RoleParams *, const int32_t *, int, int, bool, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, const uint8_t *)
 #define LUTLDPC_FAST_LAUNCHERS(X)                                                                                                           \
-    X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
-    X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
-    X template bool launch_vn_fast<TT_DEC, 1>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
-    X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, FastParams, int, int, int, int, int, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *, int, int, int); \
-    X template bool launch_cn_fast<1>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
-    X template bool launch_cn_fast<2>(hipStream_t, int, int, int, int, int, int, int, int, uint8_t *, const uint32_t *, uint32_t *, const int32_t *, int);    \
+    X template bool launch_vn_fast<TT_VAR, 1>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
+    X template bool launch_vn_fast<TT_VAR, 2>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
+    X template bool launch_vn_fast<TT_DEC, 1>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
+    X template bool launch_vn_fast<TT_DEC, 2>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint8_t *, uint8_t *, const uint32_t *, uint32_t *, const uint8_t *, const int32_t *); \
+    X template bool launch_cn_fast<1>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
+    X template bool launch_cn_fast<2>(hipStream_t, const FastParams &, const FastParams *, uint8_t *, const uint32_t *, uint32_t *, const int32_t *);    \
     X template void launch_fused<1, 0> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 0> LUTLDPC_FUSED_SIG; \
     X template void launch_fused<1, 1> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 1> LUTLDPC_FUSED_SIG; \
     X template void launch_fused<1, 2> LUTLDPC_FUSED_SIG; X template void launch_fused<2, 2> LUTLDPC_FUSED_SIG; \

@@ -82,7 +82,7 @@ __device__ __forceinline__ int cell_from_bucket(const uint64_t *thr_lds, const u
 // adds the slicer errors of each frame to stats[f][3].  One thread = 4*PACK frames x a run of
 // code-bit pairs.  codewords (frame-major [B][N], may be null = all-zero codeword): the sent bits.
 template <int PACK>
-__global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint64_t frame0,
+__global__ __launch_bounds__(256) void sample_labels_kernel(const ChannelCells *__restrict__ Cp, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint64_t frame0,
                                                             int B, int N, const uint8_t *__restrict__ codewords, uint8_t *__restrict__ cha_t,
                                                             uint8_t *__restrict__ msg_t, int32_t *__restrict__ stats, int pairs_per_thread)
 {
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void sample_labels_kernel(ChannelCells C, uint
     __shared__ uint64_t thr_lds[kMaxCells];
     __shared__ uint32_t attr_lds[kMaxCells];                        // per cell: cha | neg << 7 | msg << 8 | cha_m << 16 | msg_m << 24 (labels < 128)
     __shared__ uint8_t first_lds[1 << kBucketBits];
+    const ChannelCells &C = *Cp;                                    // (device memory: the argument segment stays small)
     const int n_thr = C.n_cells - 1;
     if (threadIdx.x < kMaxCells) {
         const int t = threadIdx.x < C.n_cells ? threadIdx.x : 0;

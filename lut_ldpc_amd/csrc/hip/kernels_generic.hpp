@@ -18,13 +18,14 @@ namespace lutldpc {
 // ------------------------------------------------------------------------------------------
 template <int KIND, bool LDS_TAB, int PACK>
 __global__ __launch_bounds__(64) void tree_pass_kernel(
-    PassParams P, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
+    const PassParams *__restrict__ Pp, uint8_t *__restrict__ msgs, const uint8_t *__restrict__ cha, uint8_t *__restrict__ hard,
     const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w, const Op *__restrict__ ops,
     const uint8_t *__restrict__ tables, const int32_t *__restrict__ node_list,
     const int32_t *__restrict__ node_ptr,   // VAR/DEC: first edge of each VN ; CHK: offset of each CN in cn_idx
     const int32_t *__restrict__ cn_idx, int out_slots)
 {
     extern __shared__ uint32_t lds[];
+    const PassParams &P = *Pp;           // (pass parameters in device memory: the argument segment stays a handful of pointers)
     const int lane = threadIdx.x;
     const int g = blockIdx.x / P.blocks_per_group;
     const int b = blockIdx.x - g * P.blocks_per_group;
@@ -151,9 +152,10 @@ __global__ __launch_bounds__(64) void tree_pass_kernel(
 // ------------------------------------------------------------------------------------------
 template <int PACK>
 __global__ __launch_bounds__(64) void cn_minsum_generic_kernel(
-    PassParams P, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
+    const PassParams *__restrict__ Pp, uint8_t *__restrict__ msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ node_list, const int32_t *__restrict__ cn_ptr, const int32_t *__restrict__ cn_idx)
 {
+    const PassParams &P = *Pp;
     const int lane = threadIdx.x;
     const int g = blockIdx.x / P.blocks_per_group;
     const int b = blockIdx.x - g * P.blocks_per_group;
@@ -295,6 +297,20 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const uint8_t *__res
 //                 frames 4*PACK*L + k of one quad c) hit 32 different banks;
 //   registers   : 4x4 byte transposes with v_perm_b32 turn "4 nodes of 4 frames" into "4 frames of one node",
 //                 the dword a lane owns in a row (PACK = 2: two of them merged as low / high nibbles).
+// XCD-aware block order of the transposes.  A block moves 128 nodes x one frame group; its frame-major side is one 128-byte
+// segment per frame at a stride of N bytes, so unless N is a multiple of 128 every segment straddles two 128-byte lines and
+// shares each with the block of the neighbouring node range.  Blocks are dealt round-robin to the 8 XCDs (one L2 each): with the
+// plain (x, y) order the two halves of a line are fetched (written) by two different L2s -- measured 3.72 GB read for 2.12 GB of
+// input.  Remapped, the blocks of one XCD cover a CONTIGUOUS range of (group, node block): the neighbour that shares a line runs
+// on the same XCD a few blocks later and finds it in that L2.
+__device__ __forceinline__ void xcd_block(int &bx, int &by) {
+    const int gx = (int)gridDim.x, total = gx * (int)gridDim.y, lin = (int)blockIdx.y * gx + (int)blockIdx.x;
+    const int per = total / 8;
+    int nl = lin;
+    if (lin < per * 8) nl = (lin & 7) * per + (lin >> 3);         // (the last total % 8 blocks keep their place)
+    bx = nl % gx; by = nl / gx;
+}
+
 __device__ __forceinline__ void transpose4x4(uint32_t (&d)[4]) {
     const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);
     const uint32_t c = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u), e = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
@@ -307,7 +323,9 @@ __global__ __launch_bounds__(256) void transpose_in_vec_kernel(const uint8_t *__
 {
     constexpr int F = kRowBytes * PACK, FPL = 4 * PACK;     // frames per group / per lane
     __shared__ uint32_t tile[F * 32];
-    const int g = blockIdx.y, n0 = blockIdx.x * 128, t = threadIdx.x;
+    int bx, by;
+    xcd_block(bx, by);
+    const int g = by, n0 = bx * 128, t = threadIdx.x;
     const int c = t & 31, fq = t >> 5;
     const uint32_t lim = (uint32_t)(limit - 1);
     for (int f0 = fq; f0 < F; f0 += 64) {                   // eight loads in flight per thread
@@ -349,7 +367,9 @@ __global__ __launch_bounds__(256) void transpose_out_vec_kernel(const uint8_t *_
 {
     constexpr int F = kRowBytes * PACK, FPL = 4 * PACK;
     __shared__ uint32_t tile[F * 32];
-    const int g = blockIdx.y, n0 = blockIdx.x * 128, t = threadIdx.x;
+    int bx, by;
+    xcd_block(bx, by);
+    const int g = by, n0 = bx * 128, t = threadIdx.x;
     const int lane = t & 63;
     for (int q = t >> 6; q < 32; q += 4) {
         uint32_t x[4] = {0, 0, 0, 0};

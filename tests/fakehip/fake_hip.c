@@ -158,7 +158,7 @@ hipError_t hipLaunchKernel(const void *func, dim3_t g, dim3_t b, void **args, si
     if (e) return e;
     int known = 0;
     LOCK();
-    for (int i = 0; i < g_nfuncs; i++) if (g_funcs[i].host == func) { g_by_func[i]++; known = 1; break; }
+    for (int i = 0; i < g_nfuncs; i++) if (g_funcs[i].host == func) { g_by_func[i]++; known = 1; if (getenv("FAKEHIP_TRACE")) fprintf(stderr, "launch %s\n", g_funcs[i].name); break; }
     g_launches += known;
     UNLOCK();
     if (!known) return fail("hipLaunchKernel: function was never registered");
