@@ -604,6 +604,34 @@ def main():
                                 "frontend_ms_per_step": pf["frontend"]["ms"] / args.frame_loop_steps,
                                 "frame_errors_last_step": int((st[:, 1] != 0).sum()),
                                 "note": "device sampler (Philox4x32-10 cell sampler) + decode + BER/FER counting, zero codeword"}
+        if world == 1:
+            # the same loop as the C++ ber_sim drives it (ber_sim_multi.cpp, default two lanes per device): two simulation objects with
+            # their own decoder handle and stream on two host threads -- while one lane's decode occupies the device the other lane's
+            # sampler runs and its counters travel back; frames are Philox-addressed, the lanes take alternate batches
+            import threading
+            cd2 = L.Codec(ROOT / "data" / "codes" / f"{alist}.alist", known_rank=known_rank, device=local)
+            cd2.design_luts(sigma2=sigma * sigma, max_iters=max_iter, nq_cha=1 << qc, nq_msg=1 << qm, **extra)
+            cd2.set_exit_conditions(max_iter, psc, psc)
+            if qcha_map is not None:
+                cd2.set_initial_message_mode(1)
+            lanes = [cd, cd2]
+            for ln in lanes:
+                ln.sim_batch(snr, 99, 0, 0, B)
+            per_lane = args.frame_loop_steps
+
+            def lane(i):
+                for k in range(per_lane):
+                    lanes[i].sim_batch(snr, 99, 0, (1 + 2 * k + i) * B, B)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=lane, args=(i,)) for i in range(2)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            t_two = time.perf_counter() - t1
+            result["frame_loop"]["two_lanes_codewords_per_s_per_gpu"] = 2 * per_lane * B / t_two
+            cd2.close()
     if args.as_shipped_steps > 0 and not psc:
         # The reference's default mode (parity_check_iter = true: exit test every iteration, src/LDPC_BER_Sim.cpp:71,500) on
         # frames 0.4 dB above the design point, where they converge: reported beside `value`, never instead of it.

@@ -220,7 +220,11 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
         emit_int_array(o, "kSet", R.iter_set);
     }
     const int tid_items_note = 0; (void)tid_items_note;
-    o << "    const int tid = threadIdx.x;\n    const int q0 = blockIdx.x * S;\n"
+    // XCD-aware set order: workgroups are dealt round-robin to the 8 XCDs (one L2 each), and a workgroup reads / writes 4 * S bytes of
+    // every label row -- a 64-byte sector of a row holds 16 sets.  Giving XCD k the contiguous sets [k * Q/8, (k+1) * Q/8) makes the
+    // workgroups that share a sector neighbours in time on ONE L2 (measured before: 549 MB of fabric reads for 61 MB of labels).
+    o << "    const int tid = threadIdx.x;\n    const int nb = (int)gridDim.x;\n"
+      << "    const int bid = (nb & 7) == 0 ? ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;\n    const int q0 = bid * S;\n"
       << "    const int max_iters = A.max_iters;\n    const bool psc = A.psc != 0;\n"
       << "    // ---- which frames of the sets decode (frame_state_kernel mode 0 ran before: ST_ACTIVE / ST_PAD)\n"
       << "    if (tid < S) {\n        const int q = q0 + tid;\n        uint32_t am[PACK];\n"
@@ -317,7 +321,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
           << "            const uint32_t a = L_act[s];\n            if (!a) continue;\n"
           << "            const int32_t *nd = A.idx + " << C.nidx_off << " + j;\n"
           << "            uint32_t acc = 0u;\n#pragma unroll 8\n            for (int k = 0; k < " << C.deg << "; k++) acc ^= M[s * E + nd[k * " << C.n << "]];\n"
-          << "            const uint32_t f = acc & a;\n            if (f) atomicOr(&L_fail[s], f);\n        }\n";
+          << "            res_flag<PACK>(L_fail, s, acc & a);\n        }\n";
     }
     o << "    };\n";
     // exit test of the sets: frames that are active and did not fail leave with iteration code `value` (state `st`);
@@ -358,7 +362,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) e[k] = ed[k * ES];\n"
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) x[k] = Ms[e[k]];\n"
                   << "            const uint32_t tn = res_minsum<" << C.deg << ", PACK>(x, r, sbit, SB, LOW);\n"
-                  << "            if (chk) { const uint32_t f = (tn >> sbit) & a; if (f) atomicOr(&L_fail[s], f); }\n"
+                  << "            if (chk) res_flag<PACK>(L_fail, s, (tn >> sbit) & a);\n"
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) Ms[e[k]] = bfi(am, r[k], x[k]);\n";
             } else {
                 // wide checks: two sweeps over the check's edges (the messages are re-read from LDS instead of held in registers)
@@ -369,7 +373,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "                const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
                   << "                min2 = k == 0 ? LOW : bfi(k2, hi, min2);\n                min1 = k == 0 ? mag : lo;\n            }\n"
                   << "            const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
-                  << "            if (chk) { const uint32_t f = (tn >> sbit) & a; if (f) atomicOr(&L_fail[s], f); }\n"
+                  << "            if (chk) res_flag<PACK>(L_fail, s, (tn >> sbit) & a);\n"
                   << "            const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
                   << "                const int ek = ed[k * ES];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
                   << "                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
@@ -406,7 +410,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
               << "            switch (kChkVar" << c << "[set]) {\n";
             for (size_t v = 0; v < bodies.size(); v++) o << "            case " << v << ": {\n" << bodies[v] << "            } break;\n";
             o << "            default: break;\n            }\n"
-              << "            if (chk) { const uint32_t f = par_w & a; if (f) atomicOr(&L_fail[s], f); }\n"
+              << "            if (chk) res_flag<PACK>(L_fail, s, par_w & a);\n"
               << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) Ms[e[k]] = bfi(am, out[k], x[k]);\n        }\n";
         }
     }
@@ -459,7 +463,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                     o << "                    hardw = res_lt<PACK>(out[0], nzo);\n#pragma unroll\n                    for (int k = 1; k < " << deg << "; k++) diff |= res_lt<PACK>(out[k], nzo) ^ hardw;\n"
                       << "                    const uint32_t f = diff & a;\n";
                 }
-                o << "                    if (f) atomicOr(&L_fail[sv], f);\n"
+                o << "                    res_flag<PACK>(L_fail, sv, f);\n"
                   << "                    hard" << it.sfx << " = bfi(am, hardw, hard" << it.sfx << ");\n                }\n"
                   << "#pragma unroll\n                for (int k = 0; k < " << deg << "; k++) M[ma" << it.sfx << " + k] = bfi(am, out[k], raw[k]);\n";
             }

@@ -72,6 +72,26 @@ __device__ __forceinline__ uint32_t res_lt(uint32_t x, uint32_t t) {
     return pack_halves<PACK>(r);
 }
 
+// Raise the failed-frame flags `f` (one bit per element) of set `s` in the workgroup's flag words.  In the first iterations nearly
+// every item has a failing frame, and the lanes of a wave mostly work on the same set: 64 lanes doing an LDS atomic on ONE word
+// serialise (64 LDS cycles per wave-instruction, a third of a degree-3 item's whole LDS time).  So the wave first ORs its flags
+// together -- one ballot per frame position -- and a single lane posts the result; a wave that straddles two sets falls back to
+// per-lane atomics.
+template <int PACK>
+__device__ __forceinline__ void res_flag(uint32_t *fail_words, int s, uint32_t f) {
+    const unsigned long long any = __ballot(f != 0u);
+    if (!any) return;
+    const int first = (int)__builtin_ctzll(any);               // the first lane with a flag to raise (wave-uniform)
+    const int s0 = __builtin_amdgcn_readlane(s, first);
+    if (__ballot(f != 0u && s != s0) == 0ull) {
+        constexpr int BITS = 8 / PACK, F = 4 * PACK;
+        uint32_t r = 0u;
+#pragma unroll
+        for (int n = 0; n < F; n++) if (__ballot((f >> (n * BITS)) & 1u)) r |= 1u << (n * BITS);
+        if ((int)(threadIdx.x & 63) == first) atomicOr(&fail_words[s0], r);
+    } else if (f) atomicOr(&fail_words[s], f);
+}
+
 // element mask (0xF / 0xFF per frame) from one flag bit per element
 template <int PACK>
 __device__ __forceinline__ uint32_t res_mask(uint32_t one_bits) { return one_bits * (PACK == 2 ? 0xFu : 0xFFu); }
