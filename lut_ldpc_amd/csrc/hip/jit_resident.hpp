@@ -44,6 +44,7 @@ static_assert(sizeof(ResidentArgs) <= 128, "kernel arguments stay small (DESIGN.
 struct ResidentClass { int deg = 0, n = 0, idx_off = 0, nidx_off = 0; };
 struct ResidentSpec {
     int pack = 2, N = 0, E = 0, S = 1, NT = 1024, I = 0, nq_cha = 16, min_lut = 1;
+    int xcd = 1;                                             // XCD-aware set order (0: workgroup b takes sets b * S ...)
     int U = 0;                                               // frames per trip of the look-up loops (0: 2 up to degree 8, else 1)
     std::vector<int> nq_msg, iter_set;                       // per iteration
     std::vector<ResidentClass> vcls, ccls;
@@ -224,7 +225,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     // every label row -- a 64-byte sector of a row holds 16 sets.  Giving XCD k the contiguous sets [k * Q/8, (k+1) * Q/8) makes the
     // workgroups that share a sector neighbours in time on ONE L2 (measured before: 549 MB of fabric reads for 61 MB of labels).
     o << "    const int tid = threadIdx.x;\n    const int nb = (int)gridDim.x;\n"
-      << "    const int bid = (nb & 7) == 0 ? ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;\n    const int q0 = bid * S;\n"
+      << "    const int bid = (" << (R.xcd ? "(nb & 7) == 0" : "false") << ") ? ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;\n    const int q0 = bid * S;\n"
       << "    const int max_iters = A.max_iters;\n    const bool psc = A.psc != 0;\n"
       << "    // ---- which frames of the sets decode (frame_state_kernel mode 0 ran before: ST_ACTIVE / ST_PAD)\n"
       << "    if (tid < S) {\n        const int q = q0 + tid;\n        uint32_t am[PACK];\n"
