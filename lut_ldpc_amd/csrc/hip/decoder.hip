@@ -168,7 +168,7 @@ struct lutldpc_decoder {
     // LDS-resident decoder (jit_resident.hpp): codes whose edge messages fit the LDS of a compute unit are decoded by ONE generated
     // kernel per decode -- all iterations inside, no HBM traffic between the labels and the decided bits.  LUTLDPC_RESIDENT=0: off
     // (the streaming kernels run instead); LUTLDPC_RESIDENT_S / _NT force the sets per workgroup / threads per workgroup.
-    int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0, resident_xcd = 1;
+    int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0, resident_xcd = 1, resident_flag_reduce = -1, resident_waves_eu = 0;
     bool resident_ok = false;
     struct ResidentPlan { int S = 0, NT = 0, lds = 0; const JitKernel *k = nullptr; };
     std::map<int, ResidentPlan> resident_plans;       // by frame groups
@@ -1308,7 +1308,13 @@ constexpr int kLdsPerCu = 160 * 1024, kResidentCus = 256;
 ResidentSpec resident_spec(const lutldpc_decoder *d, int S, int NT) {
     ResidentSpec R;
     R.pack = d->pack; R.N = d->nvar; R.E = d->E; R.S = S; R.NT = NT; R.I = d->max_iters_created; R.nq_cha = d->Nq_Cha; R.min_lut = d->min_lut;
-    R.nq_msg = d->Nq_Msg; R.iter_set = d->iter_set; R.U = d->resident_U; R.xcd = d->resident_xcd;
+    R.nq_msg = d->Nq_Msg; R.iter_set = d->iter_set; R.U = d->resident_U; R.xcd = d->resident_xcd; R.waves_eu = d->resident_waves_eu;
+    {   // wave-reduced exit-test flags cost registers in the item bodies: +7 % on (3,6) N=10000 as shipped, but with the wide trees of
+        // N=500 (degree 17: 168 registers, one wave per SIMD less) 13.5 -> 10.2 M codewords/s -- only where the trees are small
+        int max_vn = 0;
+        for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
+        R.flag_reduce = d->resident_flag_reduce >= 0 ? d->resident_flag_reduce : (max_vn <= 8 ? 1 : 0);
+    }
     for (size_t i = 0; i < d->vclass.size(); i++) R.vcls.push_back({d->vclass[i].deg, (int)d->vclass[i].nodes.size(), d->vn_tidx_off[i], 0});
     for (size_t i = 0; i < d->cclass.size(); i++) R.ccls.push_back({d->cclass[i].deg, (int)d->cclass[i].nodes.size(), d->cn_tidx_off[i], d->cn_tnidx_off[i]});
     const size_t ns = d->var_plan.size();
@@ -1728,6 +1734,8 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_RESIDENT_S")) { int v = atoi(e); if (v >= 1 && v <= 64) d->resident_force_S = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_NT")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) d->resident_force_NT = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_XCD")) d->resident_xcd = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_RESIDENT_FLAG_REDUCE")) d->resident_flag_reduce = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_RESIDENT_WAVES_EU")) { int v = atoi(e); if (v >= 0 && v <= 8) d->resident_waves_eu = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_U")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) d->resident_U = v; }
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;

@@ -44,6 +44,8 @@ static_assert(sizeof(ResidentArgs) <= 128, "kernel arguments stay small (DESIGN.
 struct ResidentClass { int deg = 0, n = 0, idx_off = 0, nidx_off = 0; };
 struct ResidentSpec {
     int pack = 2, N = 0, E = 0, S = 1, NT = 1024, I = 0, nq_cha = 16, min_lut = 1;
+    int flag_reduce = 1;                                     // exit-test flags ORed over the wave before the LDS atomic (0: per-lane atomics)
+    int waves_eu = 0;                                        // amdgpu_waves_per_eu lower bound (0: compiler's choice)
     int xcd = 1;                                             // XCD-aware set order (0: workgroup b takes sets b * S ...)
     int U = 0;                                               // frames per trip of the look-up loops (0: 2 up to degree 8, else 1)
     std::vector<int> nq_msg, iter_set;                       // per iteration
@@ -200,7 +202,8 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     o << kCommonHeaderText << "\n" << kResidentHeaderText << "\nusing namespace lutldpc;\n"
       << "struct ResidentArgs { const uint8_t *cha, *msg0; uint8_t *hard; uint8_t *state; int32_t *iters; const uint8_t *tables; const int32_t *idx;\n"
       << "                      int32_t n_sets, max_iters, psc, pisc, pad; };\n"
-      << "extern \"C\" __global__ __launch_bounds__(" << NT << ") void lutldpc_jit_pass(ResidentArgs A)\n{\n"
+      << "extern \"C\" __global__ __launch_bounds__(" << NT << ") " << (R.waves_eu > 0 ? "__attribute__((amdgpu_waves_per_eu(" + S_(R.waves_eu) + ", 8))) " : "")
+      << "void lutldpc_jit_pass(ResidentArgs A)\n{\n"
       << "    constexpr int PACK = " << PACK << ", BITS = " << BITS << ", F = 4 * PACK, S = " << S << ", NT = " << NT << ", E = " << E << ", N = " << N << ", I = " << I << ";\n"
       << "    constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;\n"
       << "    constexpr uint32_t NZC = " << R.nq_cha / 2 << "u;\n"
@@ -211,6 +214,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
       << "    uint8_t *const TV = reinterpret_cast<uint8_t *>(LDS_ALL);\n    uint8_t *const TC = TV + TVB;\n"
       << "    uint32_t *const L_fail = LDS_ALL + (TVB + TCB) / 4, *const L_act = L_fail + S;\n"
       << "    uint32_t *const M = L_act + S;\n"
+      << "    auto flag = [&](int s_, uint32_t f_) { " << (R.flag_reduce ? "res_flag<PACK>(L_fail, s_, f_);" : "if (f_) atomicOr(&L_fail[s_], f_);") << " };\n"
       << "    (void)I; (void)N; (void)TC;\n";
     // ---- per-iteration / per-set constants
     {
@@ -322,7 +326,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
           << "            const uint32_t a = L_act[s];\n            if (!a) continue;\n"
           << "            const int32_t *nd = A.idx + " << C.nidx_off << " + j;\n"
           << "            uint32_t acc = 0u;\n#pragma unroll 8\n            for (int k = 0; k < " << C.deg << "; k++) acc ^= M[s * E + nd[k * " << C.n << "]];\n"
-          << "            res_flag<PACK>(L_fail, s, acc & a);\n        }\n";
+          << "            flag(s, acc & a);\n        }\n";
     }
     o << "    };\n";
     // exit test of the sets: frames that are active and did not fail leave with iteration code `value` (state `st`);
@@ -363,7 +367,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) e[k] = ed[k * ES];\n"
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) x[k] = Ms[e[k]];\n"
                   << "            const uint32_t tn = res_minsum<" << C.deg << ", PACK>(x, r, sbit, SB, LOW);\n"
-                  << "            if (chk) res_flag<PACK>(L_fail, s, (tn >> sbit) & a);\n"
+                  << "            if (chk) flag(s, (tn >> sbit) & a);\n"
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) Ms[e[k]] = bfi(am, r[k], x[k]);\n";
             } else {
                 // wide checks: two sweeps over the check's edges (the messages are re-read from LDS instead of held in registers)
@@ -374,7 +378,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "                const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
                   << "                min2 = k == 0 ? LOW : bfi(k2, hi, min2);\n                min1 = k == 0 ? mag : lo;\n            }\n"
                   << "            const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
-                  << "            if (chk) res_flag<PACK>(L_fail, s, (tn >> sbit) & a);\n"
+                  << "            if (chk) flag(s, (tn >> sbit) & a);\n"
                   << "            const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
                   << "                const int ek = ed[k * ES];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
                   << "                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
@@ -411,7 +415,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
               << "            switch (kChkVar" << c << "[set]) {\n";
             for (size_t v = 0; v < bodies.size(); v++) o << "            case " << v << ": {\n" << bodies[v] << "            } break;\n";
             o << "            default: break;\n            }\n"
-              << "            if (chk) res_flag<PACK>(L_fail, s, par_w & a);\n"
+              << "            if (chk) flag(s, par_w & a);\n"
               << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) Ms[e[k]] = bfi(am, out[k], x[k]);\n        }\n";
         }
     }
@@ -464,7 +468,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                     o << "                    hardw = res_lt<PACK>(out[0], nzo);\n#pragma unroll\n                    for (int k = 1; k < " << deg << "; k++) diff |= res_lt<PACK>(out[k], nzo) ^ hardw;\n"
                       << "                    const uint32_t f = diff & a;\n";
                 }
-                o << "                    res_flag<PACK>(L_fail, sv, f);\n"
+                o << "                    flag(sv, f);\n"
                   << "                    hard" << it.sfx << " = bfi(am, hardw, hard" << it.sfx << ");\n                }\n"
                   << "#pragma unroll\n                for (int k = 0; k < " << deg << "; k++) M[ma" << it.sfx << " + k] = bfi(am, out[k], raw[k]);\n";
             }
