@@ -57,7 +57,9 @@ WORKLOADS = {
     "c1": ("rate0.50_dv02-17_dc08-09_lut_q4_N500", 0.88, 50, 4, 4, 16384, {}, 250),
     # params/ber.ini.regular.example: (6,32) N=2048, rank 325, 3-bit messages, 8 iterations, trees from a file, QCHA
     # initial messages, design at Eb/N0 = 3.9 dB (sigma^2 = 1 / (2 R 10^0.39)); c5chk: CHKTREE check update (min_lut = false)
-    "c5": ("rate0.84_reg_v6c32_N2048", 0.6159, 8, 4, 3, 32768, dict(tree_method="filename=" + str(ROOT / "data" / "trees" / "6_32_wide.ini")), 325),
+    # (36864 frames = 4608 sets of 8 = six full rounds of the 768 workgroups the chip holds at once (three 51 KB workgroups per
+    # compute unit): 32768 frames end on a sixth round that is one third full, -11 %)
+    "c5": ("rate0.84_reg_v6c32_N2048", 0.6159, 8, 4, 3, 36864, dict(tree_method="filename=" + str(ROOT / "data" / "trees" / "6_32_wide.ini")), 325),
     "c5chk": ("rate0.84_reg_v6c32_N2048", 0.6159, 8, 4, 3, 32768,
               dict(tree_method="filename=" + str(ROOT / "data" / "trees" / "6_32_wide.ini"), min_lut=False), 325),
 }
@@ -678,7 +680,7 @@ def main():
         # the headline decoder's buffers (7 GB at 32768 frames) go first; its outputs are kept for the oracle check below
         keep_bits, keep_iters = out_bits[:n_host].cpu().numpy(), out_iters[:n_host].cpu().numpy()
         configs = {}
-        for wl, Bc in (("c2", 4096), ("c5", 32768), ("c5chk", 32768), ("c1", 16384), ("twin", 32768)):
+        for wl, Bc in (("c2", 4096), ("c5", 36864), ("c5chk", 32768), ("c1", 16384), ("twin", 32768)):
             configs[wl] = quick_config(L, torch, wl, Bc, local)
     result["configs"] = configs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -2,18 +2,20 @@
 """Randomised parity run on the GPU box (test infrastructure: uses the oracle as the checker, like tests/): random irregular
 graphs, alphabets, iteration counts, batch sizes and exit modes through the default path, every bit and iteration code
 against the oracle.  Usage: python tests/fuzz_parity.py [cases] [seed]"""
-import pathlib, sys, tempfile
+import os, pathlib, sys, tempfile
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))   # (this file lives in tests/: only tests may use the oracle)
 from helpers import awgn_labels, compare, product_decoder, write_random_alist     # noqa: E402
 from oracle import oracle as orc                                                   # noqa: E402
 
-import os
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 COMPACT = "--compact" in sys.argv      # many frame groups, compaction of the surviving frames forced on with random check points
 BP = "--bp" in sys.argv                # the [BP] comparison decoder instead of the LUT decoder (GPU against the oracle's statement of it)
+GEOM = "--resident-geom" in sys.argv   # LDS-resident decoder (the default for these code sizes) with a random workgroup geometry per case
+if COMPACT:
+    os.environ["LUTLDPC_RESIDENT"] = "0"   # (compaction belongs to the streaming kernels)
 bad = 0
 for c in range(cases):
     N = int(rng.integers(200, 1600))
@@ -95,11 +97,20 @@ for c in range(cases):
             (cd.lut_decode_batch_flat if COMPACT else cd.lut_decode_batch)(cha, msg)
         print(f"case {c}: N={N} M={M} dv={dvc} dc={sorted(set(dc.tolist()))} nq={nqc}/{nq_vec.tolist()} I={I} B={B} {extra}: oracle alone ok", flush=True)
         continue
-    dec = product_decoder(cd)
+    if GEOM:
+        r3 = np.random.default_rng(7000 + c)
+        os.environ["LUTLDPC_RESIDENT_S"] = str(int(r3.integers(1, 9)))
+        os.environ["LUTLDPC_RESIDENT_NT"] = str(int(r3.choice([256, 512, 768, 1024])))
+        os.environ["LUTLDPC_RESIDENT"] = "2"
+        os.environ["LUTLDPC_COMPOSE"] = str(int(r3.integers(0, 2)))
+    try:
+        dec = product_decoder(cd)
+    except Exception as e:
+        print(f"case {c}: decoder refused ({str(e)[:120]}), skipped"); continue
     try:
         for psc, pisc in [(True, True), (True, False), (False, False)]:
             it = compare(cd, dec, cha, msg, psc, pisc, flat=COMPACT)
-        print(f"case {c}: N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} nq={nqc}/{nqm} I={I} B={B} bucket={dec.describe()['fused_bucket']} skew={dec.describe()['skewed_pipeline']} {extra if extra else ''} nq_msg={sorted(set(nq_vec.tolist()))} {('compaction ' + str(dec.describe()['compaction']) + ' first/every/keep ' + os.environ['LUTLDPC_COMPACT_FIRST'] + '/' + os.environ['LUTLDPC_COMPACT_EVERY'] + '/' + os.environ['LUTLDPC_COMPACT_KEEP']) if COMPACT else ''} ok, iteration codes {sorted(set(it.tolist()))[:5]}")
+        print(f"case {c}: N={N} M={M} dv={sorted(set(dv.tolist()))} dc={sorted(set(dc.tolist()))} nq={nqc}/{nqm} I={I} B={B} bucket={dec.describe()['fused_bucket']} skew={dec.describe()['skewed_pipeline']} resident={dec.describe()['resident']}{(' geom ' + os.environ['LUTLDPC_RESIDENT_S'] + 'x' + os.environ['LUTLDPC_RESIDENT_NT'] + ' compose ' + os.environ['LUTLDPC_COMPOSE']) if GEOM else ''} {extra if extra else ''} nq_msg={sorted(set(nq_vec.tolist()))} {('compaction ' + str(dec.describe()['compaction']) + ' first/every/keep ' + os.environ['LUTLDPC_COMPACT_FIRST'] + '/' + os.environ['LUTLDPC_COMPACT_EVERY'] + '/' + os.environ['LUTLDPC_COMPACT_KEEP']) if COMPACT else ''} ok, iteration codes {sorted(set(it.tolist()))[:5]}")
     except AssertionError as e:
         bad += 1
         print(f"case {c}: MISMATCH N={N} M={M} dv={dvc} nq={nqc}/{nqm} I={I} B={B}: {str(e)[:200]}")
