@@ -112,9 +112,11 @@ COMPOSED = 16      # kind + 16: the program of the same tree after exact table c
 
 @pytest.mark.parametrize("name", ["n500_q4_i8", "reg36_n1000_mixed", "reg36_n1000_q3_chklut", "reg36_n1000_rootonly", "reg36_n1000_high",
                                   "c5_chklut", "dvbs2_q4_i6"])
-def test_composed_programs_match_oracle_tree_walk(name):
-    """Table composition folds a LUT node into its parent (T'[...] = T_P[..., T_X[...], ...]): fewer look-ups, the same function.
+def test_composed_programs_match_oracle_tree_walk(name, monkeypatch):
+    """(LUTLDPC_COMPOSE=1: off by default -- exact, but the 4 KB tables cost more LDS bank conflicts than the saved look-ups are worth.)
+    Table composition folds a LUT node into its parent (T'[...] = T_P[..., T_X[...], ...]): fewer look-ups, the same function.
     Every composed program against the oracle's queue / recursion walk of the ORIGINAL tree on random inputs."""
+    monkeypatch.setenv("LUTLDPC_COMPOSE", "1")
     cd = oracle_codec(name)
     dec = product_decoder(cd, device=-1)
     rng = np.random.default_rng(12)
@@ -149,8 +151,9 @@ def _check_composed(cd, dec, kind, tree_set, cls, deg, n_trials, rng, k_in, k_ch
         assert (want == got).all(), (kind, tree_set, cls, x, want, got)
 
 
-def test_composition_look_up_counts():
+def test_composition_look_up_counts(monkeypatch):
     """Balanced trees: degree 3 -> three 3-input look-ups instead of six; degree 8 -> 20 instead of 34."""
+    monkeypatch.setenv("LUTLDPC_COMPOSE", "1")
     cd = oracle_codec("dvbs2_q4_i6")
     dec = product_decoder(cd, device=-1)
     degs = sorted(set(cd.code.dv.tolist()))
