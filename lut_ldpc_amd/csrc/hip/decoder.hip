@@ -168,6 +168,11 @@ struct lutldpc_decoder {
     // LDS-resident decoder (jit_resident.hpp): codes whose edge messages fit the LDS of a compute unit are decoded by ONE generated
     // kernel per decode -- all iterations inside, no HBM traffic between the labels and the decided bits.  LUTLDPC_RESIDENT=0: off
     // (the streaming kernels run instead); LUTLDPC_RESIDENT_S / _NT force the sets per workgroup / threads per workgroup.
+    // frame-major label / bit buffers of the current decode_device call, handed to the resident kernel (it reads and writes them
+    // itself: no transposes); null = rows
+    const uint8_t *fm_cha = nullptr, *fm_msg0 = nullptr;
+    uint8_t *fm_bits = nullptr;
+    int resident_fm = 1;           // LUTLDPC_RESIDENT_FM=0: always through the row layout
     int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0, resident_xcd = 1, resident_flag_reduce = -1, resident_waves_eu = 0;
     bool resident_ok = false;
     struct ResidentPlan { int S = 0, NT = 0, lds = 0; const JitKernel *k = nullptr; };
@@ -1415,13 +1420,14 @@ int resident_plan_for(lutldpc_decoder *d, int G, lutldpc_decoder::ResidentPlan *
     return LUTLDPC_OK;
 }
 
-int launch_resident(lutldpc_decoder *d, int G) {
+int launch_resident(lutldpc_decoder *d, int G, int B) {
     lutldpc_decoder::ResidentPlan *pl = nullptr;
     if (int rc = resident_plan_for(d, G, &pl)) return rc;
     Timed t(d, LUTLDPC_K_RESIDENT);
     ResidentArgs A{};
     A.cha = d->d_cha_t.p; A.msg0 = d->d_msg0_t.p; A.hard = d->d_hard.p; A.state = d->d_state.p; A.iters = d->d_iters.p;
     A.tables = d->d_tables.p; A.idx = d->d_fast_idx.p; A.n_sets = 64 * G; A.max_iters = d->max_iters; A.psc = d->psc; A.pisc = d->pisc;
+    A.B = B; A.fm_cha = d->fm_cha; A.fm_msg0 = d->fm_msg0; A.fm_bits = d->fm_bits; A.lim_cha = d->Nq_Cha - 1; A.lim_msg = d->Nq_Msg[0] - 1;
     void *args[] = {&A};
     const unsigned blocks = (unsigned)((64 * G + pl->S - 1) / pl->S);
     HIP_TRY(hipModuleLaunchKernel(pl->k->fn, blocks, 1, 1, (unsigned)pl->NT, 1, 1, 0, d->stream, args, nullptr));
@@ -1456,7 +1462,7 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
     if ((rc = launch_state(d, B, Bpad, 0, 0))) return rc;
     const bool tracing = d->trace.level > 1;
     if (resident_active(d) && !tracing) {         // the whole of lut_decode in one launch, messages in LDS (jit_resident.hpp)
-        if ((rc = launch_resident(d, G))) return rc;
+        if ((rc = launch_resident(d, G, B))) return rc;
         if (d->profiling && d->ev_live.size() > 8192) prof_fold(d);
         return LUTLDPC_OK;
     }
@@ -1541,7 +1547,9 @@ int decode_tiles(lutldpc_decoder *d, int B) {
         lutldpc_decoder::ResidentPlan *pl = nullptr;
         if (int rc = resident_plan_for(d, d->bpad(B) / d->tile(), &pl)) return rc;
     }
-    if (!d->use_graph || d->profiling || d->trace.level > 1) return decode_tiles_launch(d, B);
+    // (the resident decoder is ONE launch plus the state kernel: nothing to gain from a graph, and the frame-major pointers of the
+    // caller would be frozen into it)
+    if (!d->use_graph || d->profiling || d->trace.level > 1 || resident_active(d)) return decode_tiles_launch(d, B);
     const std::array<int, 4> key = {B, d->psc, d->pisc, d->max_iters};
     if (d->graphs.size() > 32 && !d->graphs.count(key)) d->drop_graphs();      // callers with ever-changing batch sizes: bound the cache
     auto &slot = d->graphs[key];
@@ -1575,16 +1583,21 @@ int decode_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg
     int rc = ensure_batch(d, B);
     if (rc) return rc;
     const int Bpad = d->bpad(B), G = Bpad / d->tile();
-    {
+    // the LDS-resident decoder reads the frame-major labels and writes the frame-major bits itself
+    const bool direct = resident_active(d) && d->resident_fm && d->trace.level <= 1;
+    if (!direct) {
         Timed t(d, LUTLDPC_K_LAYOUT);
         if ((rc = launch_transpose_in(d, d_cha, d->d_cha_t.p, B, G, d->Nq_Cha))) return rc;
         if ((rc = launch_transpose_in(d, d_msg0, d->d_msg0_t.p, B, G, d->Nq_Msg[0]))) return rc;
         LAUNCH_CHECK();
     }
-    if ((rc = decode_tiles(d, B))) return rc;
+    if (direct) { d->fm_cha = d_cha; d->fm_msg0 = d_msg0; d->fm_bits = d_out_bits; }
+    rc = decode_tiles(d, B);
+    d->fm_cha = d->fm_msg0 = nullptr; d->fm_bits = nullptr;
+    if (rc) return rc;
     {
         Timed t(d, LUTLDPC_K_LAYOUT);
-        if ((rc = launch_transpose_out(d, d->d_hard.p, d_out_bits, B, G))) return rc;
+        if (!direct && (rc = launch_transpose_out(d, d->d_hard.p, d_out_bits, B, G))) return rc;
         HIP_TRY(hipMemcpyAsync(d_out_iters, d->d_iters.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToDevice, d->stream));
     }
     return LUTLDPC_OK;
@@ -1734,6 +1747,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_RESIDENT_S")) { int v = atoi(e); if (v >= 1 && v <= 64) d->resident_force_S = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_NT")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) d->resident_force_NT = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_XCD")) d->resident_xcd = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_RESIDENT_FM")) d->resident_fm = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_RESIDENT_FLAG_REDUCE")) d->resident_flag_reduce = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_RESIDENT_WAVES_EU")) { int v = atoi(e); if (v >= 0 && v <= 8) d->resident_waves_eu = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_U")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) d->resident_U = v; }

@@ -28,7 +28,7 @@ static const char *const kResidentHeaderText =
 #include "kernels_resident.inc"
     ;
 
-struct ResidentArgs {              // kernel arguments (by value: 80 bytes)
+struct ResidentArgs {              // kernel arguments (by value: 112 bytes)
     const uint8_t *cha, *msg0;     // label rows [G][N][256 B]
     uint8_t *hard;                 // decided-bit rows
     uint8_t *state;                // per-frame state bytes
@@ -37,7 +37,13 @@ struct ResidentArgs {              // kernel arguments (by value: 80 bytes)
     const int32_t *idx;            // the decoder's dense index blob (build_fast_index)
     int32_t n_sets;                // 64 * frame groups
     int32_t max_iters, psc, pisc;
-    int32_t pad;
+    int32_t B;                     // frames of the batch (frame-major I/O: frames beyond it read as label 0)
+    // frame-major I/O (the C-ABI's own layout, [B][N] bytes): when fm_cha is set the kernel reads the labels and writes the decided
+    // bits there itself -- a thread's eight frames of a node are eight byte accesses, 64 lanes of consecutive nodes one 64-byte
+    // segment per frame -- and the three transposes around the decode disappear (9 % of a (6,32) N=2048 step)
+    const uint8_t *fm_cha, *fm_msg0;
+    uint8_t *fm_bits;
+    int32_t lim_cha, lim_msg;      // labels are clamped to the alphabets like the transposes do
 };
 static_assert(sizeof(ResidentArgs) <= 128, "kernel arguments stay small (DESIGN.md section 7.1)");
 
@@ -201,7 +207,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     std::ostringstream o;
     o << kCommonHeaderText << "\n" << kResidentHeaderText << "\nusing namespace lutldpc;\n"
       << "struct ResidentArgs { const uint8_t *cha, *msg0; uint8_t *hard; uint8_t *state; int32_t *iters; const uint8_t *tables; const int32_t *idx;\n"
-      << "                      int32_t n_sets, max_iters, psc, pisc, pad; };\n"
+      << "                      int32_t n_sets, max_iters, psc, pisc, B; const uint8_t *fm_cha, *fm_msg0; uint8_t *fm_bits; int32_t lim_cha, lim_msg; };\n"
       << "extern \"C\" __global__ __launch_bounds__(" << NT << ") " << (R.waves_eu > 0 ? "__attribute__((amdgpu_waves_per_eu(" + S_(R.waves_eu) + ", 8))) " : "")
       << "void lutldpc_jit_pass(ResidentArgs A)\n{\n"
       << "    constexpr int PACK = " << PACK << ", BITS = " << BITS << ", F = 4 * PACK, S = " << S << ", NT = " << NT << ", E = " << E << ", N = " << N << ", I = " << I << ";\n"
@@ -237,6 +243,12 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
       << "        L_act[tid] = pack_masks<PACK>(am) & ONE;\n        L_fail[tid] = 0u;\n    }\n"
       << "    __syncthreads();\n";
 
+    o << "    // frame-major access of the eight (four) frames of set q at node v: element n of the dword <-> frame res_frame_of_element(n)\n"
+      << "    auto fm_load = [&](const uint8_t *p, int q, int v, uint32_t lim) {\n        uint32_t w = 0u;\n#pragma unroll\n        for (int n = 0; n < F; n++) {\n"
+      << "            const int f = q * F + res_frame_of_element<PACK>(n);\n            uint32_t x = f < A.B ? (uint32_t)p[(size_t)f * N + v] : 0u;\n"
+      << "            x = x > lim ? lim : x;\n            w |= x << (n * BITS);\n        }\n        return w;\n    };\n"
+      << "    auto fm_store = [&](uint8_t *p, int q, int v, uint32_t w) {\n#pragma unroll\n        for (int n = 0; n < F; n++) {\n"
+      << "            const int f = q * F + res_frame_of_element<PACK>(n);\n            if (f < A.B) p[(size_t)f * N + v] = (uint8_t)((w >> (n * BITS)) & 1u);\n        }\n    };\n";
     // ---- table staging helper (all threads): bytes `len` (multiple of 4) from the blob to an LDS region
     o << "    auto stage = [&](uint8_t *dst, int off, int len) {\n"
       << "        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(A.tables + off);\n"
@@ -297,7 +309,8 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
           << "            const int s = it / " << C.n << ", j = it - s * " << C.n << ", q = q0 + s;\n"
           << "            const int32_t *vt = A.idx + " << C.idx_off << ";\n"
           << "            ma" << it.sfx << " = s * E + vt[" << C.n << " + j];\n"
-          << "            if (q < A.n_sets) cha" << it.sfx << " = *reinterpret_cast<const uint32_t *>(A.cha + ((size_t)(q >> 6) * N + (size_t)vt[j]) * kRowBytes + (q & 63) * 4);\n"
+          << "            if (q < A.n_sets) cha" << it.sfx << " = A.fm_cha ? fm_load(A.fm_cha, q, vt[j], (uint32_t)A.lim_cha)\n"
+          << "                                               : *reinterpret_cast<const uint32_t *>(A.cha + ((size_t)(q >> 6) * N + (size_t)vt[j]) * kRowBytes + (q & 63) * 4);\n"
           << "            hard" << it.sfx << " = res_lt<PACK>(cha" << it.sfx << ", NZC);\n"
           << "        }\n    }\n";
     }
@@ -345,7 +358,8 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     for (auto &it : items) {
         const ResidentClass &C = R.vcls[(size_t)it.c];
         o << "        if (ma" << it.sfx << " >= 0) {\n            const int q = q0 + sv" << it.sfx << "();\n"
-          << "            const uint32_t m0 = q < A.n_sets ? *reinterpret_cast<const uint32_t *>(A.msg0 + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4) : 0u;\n"
+          << "            const uint32_t m0 = q >= A.n_sets ? 0u : A.fm_msg0 ? fm_load(A.fm_msg0, q, nd" << it.sfx << "(), (uint32_t)A.lim_msg)\n"
+          << "                              : *reinterpret_cast<const uint32_t *>(A.msg0 + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4);\n"
           << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) M[ma" << it.sfx << " + k] = m0;\n        }\n";
     }
     if (!R.min_lut) o << "        stage_chk(kSet[0]);\n";
@@ -496,7 +510,7 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     // ---- decided bits back to their rows
     for (auto &it : items)
         o << "    if (ma" << it.sfx << " >= 0 && q0 + sv" << it.sfx << "() < A.n_sets) { const int q = q0 + sv" << it.sfx
-          << "(); *reinterpret_cast<uint32_t *>(A.hard + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4) = hard" << it.sfx << "; }\n";
+          << "(); if (A.fm_bits) fm_store(A.fm_bits, q, nd" << it.sfx << "(), hard" << it.sfx << "); else *reinterpret_cast<uint32_t *>(A.hard + ((size_t)(q >> 6) * N + (size_t)nd" << it.sfx << "()) * kRowBytes + (q & 63) * 4) = hard" << it.sfx << "; }\n";
     o << "}\n";
     src = o.str();
     return true;
