@@ -552,6 +552,9 @@ int ber_sim_main(int argc, char **argv) {
         if (const char *e = std::getenv("LUTLDPC_LANES")) lanes = std::atoi(e);
         const bool is_bp = !(ini.has_section("LUT") || codec_type == "LUT");
         if (is_bp && devices.size() == 1) lanes = 1;               // (the [BP] comparison decoder draws its noise on all host cores already)
+        // output_verbosity > 0 prints every frame's stimuli / message dumps to std::cout in frame order (src/LDPC_Code_LUT.cpp:228-238,
+        // 292-337): that text is only meaningful from ONE thread
+        if (ini.get("LUT.output_verbosity", 0) > 0) { lanes = 1; if (devices.size() > 1) devices.resize(1); }
         if (devices.size() > 1 || lanes > 1)
             return ber_sim_run_multi(params_path, base_dir, seed, custom_name, devices, lanes, exchange, false);
         std::unique_ptr<LDPC_BER_Sim> sim;
