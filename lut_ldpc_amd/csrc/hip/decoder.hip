@@ -173,7 +173,7 @@ struct lutldpc_decoder {
     const uint8_t *fm_cha = nullptr, *fm_msg0 = nullptr;
     uint8_t *fm_bits = nullptr;
     int resident_fm = 1;           // LUTLDPC_RESIDENT_FM=0: always through the row layout
-    int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0, resident_xcd = 1, resident_flag_reduce = -1, resident_waves_eu = 0;
+    int use_resident = 1, resident_force_S = 0, resident_force_NT = 0, resident_U = 0, resident_xcd = 1, resident_flag_reduce = -1, resident_waves_eu = 0, resident_cn_persistent = -1;
     bool resident_ok = false;
     struct ResidentPlan { int S = 0, NT = 0, lds = 0; const JitKernel *k = nullptr; };
     std::map<int, ResidentPlan> resident_plans;       // by frame groups
@@ -1319,6 +1319,13 @@ ResidentSpec resident_spec(const lutldpc_decoder *d, int S, int NT) {
         int max_vn = 0;
         for (auto &c : d->vclass) max_vn = std::max(max_vn, c.deg);
         R.flag_reduce = d->resident_flag_reduce >= 0 ? d->resident_flag_reduce : (max_vn <= 8 ? 1 : 0);
+        // check items keep their LDS addresses in registers when that is few registers and the trees leave room for them
+        int cn_regs = 0, max_cn = 0;
+        for (auto &c : d->cclass) { cn_regs += (int)((S * (long long)c.nodes.size() + NT - 1) / NT + 1) * c.deg; max_cn = std::max(max_cn, c.deg); }
+        // (... or the wide trees have cost the occupancy already: N=500 runs two waves per SIMD with 159 registers, +3 % with them;
+        // (6,32) N=2048 would fall from three workgroups per compute unit to two: 25.6 -> 23.5 M, off)
+        R.cn_persistent = d->resident_cn_persistent >= 0 ? d->resident_cn_persistent
+                          : (d->min_lut && max_cn <= 16 && ((max_vn <= 4 && cn_regs <= 40) || (max_vn > 12 && cn_regs <= 96)) ? 1 : 0);      // (measured: (3,6) N=10000 1.82 -> 1.94 M codewords/s fixed work, 3.7 -> 7.5 M as shipped)
     }
     for (size_t i = 0; i < d->vclass.size(); i++) R.vcls.push_back({d->vclass[i].deg, (int)d->vclass[i].nodes.size(), d->vn_tidx_off[i], 0});
     for (size_t i = 0; i < d->cclass.size(); i++) R.ccls.push_back({d->cclass[i].deg, (int)d->cclass[i].nodes.size(), d->cn_tidx_off[i], d->cn_tnidx_off[i]});
@@ -1747,6 +1754,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_RESIDENT_S")) { int v = atoi(e); if (v >= 1 && v <= 64) d->resident_force_S = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_NT")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) d->resident_force_NT = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_XCD")) d->resident_xcd = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_RESIDENT_CN_PERSISTENT")) d->resident_cn_persistent = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_RESIDENT_FM")) d->resident_fm = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_RESIDENT_FLAG_REDUCE")) d->resident_flag_reduce = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_RESIDENT_WAVES_EU")) { int v = atoi(e); if (v >= 0 && v <= 8) d->resident_waves_eu = v; }

@@ -52,6 +52,7 @@ struct ResidentSpec {
     int pack = 2, N = 0, E = 0, S = 1, NT = 1024, I = 0, nq_cha = 16, min_lut = 1;
     int flag_reduce = 1;                                     // exit-test flags ORed over the wave before the LDS atomic (0: per-lane atomics)
     int waves_eu = 0;                                        // amdgpu_waves_per_eu lower bound (0: compiler's choice)
+    int cn_persistent = 0;                                   // check items keep their edge addresses in registers for the whole decode (small regular codes)
     int xcd = 1;                                             // XCD-aware set order (0: workgroup b takes sets b * S ...)
     int U = 0;                                               // frames per trip of the look-up loops (0: 2 up to degree 8, else 1)
     std::vector<int> nq_msg, iter_set;                       // per iteration
@@ -314,6 +315,10 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
           << "            hard" << it.sfx << " = res_lt<PACK>(cha" << it.sfx << ", NZC);\n"
           << "        }\n    }\n";
     }
+    // (cn_persistent) a check item's LDS addresses (set * E + edge id) stay in registers too: a regular code of small degrees then
+    // reads NO index from global memory inside the iteration loop ((3,6) N=10000: five items x six addresses per thread)
+    struct CItem { size_t c; int r; std::string sfx; };
+    std::vector<CItem> citems;
     // check items: one sequence of slots over all check classes as well (widest checks first)
     std::vector<int> cbase(NCC, 0);
     std::vector<size_t> corder(NCC);
@@ -328,6 +333,18 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
         const int b = cbase[c];
         return "for (int it = tid + ((" + S_(b) + " - tid + NT - 1) / NT) * NT - " + S_(b) + "; it < S * " + S_(R.ccls[c].n) + "; it += NT) {\n";
     };
+    if (R.cn_persistent && R.min_lut) {
+        for (size_t c : corder) {
+            const int cnt = S * R.ccls[c].n;
+            for (int r = cbase[c] / NT; cnt > 0 && r <= (cbase[c] + cnt - 1) / NT; r++) citems.push_back({c, r, "_" + S_((long long)c) + "_" + S_(r)});
+        }
+        for (auto &ci : citems) {
+            const ResidentClass &C = R.ccls[ci.c];
+            o << "    int cs" << ci.sfx << " = -1, ce" << ci.sfx << "[" << C.deg << "];\n    {\n        const int it = tid + " << ci.r << " * NT - " << cbase[ci.c] << ";\n"
+              << "        if (it >= 0 && it < S * " << C.n << ") {\n            const int s = it / " << C.n << ", j = it - s * " << C.n << ";\n            cs" << ci.sfx << " = s;\n"
+              << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) ce" << ci.sfx << "[k] = s * E + A.idx[" << C.idx_off << " + j + k * " << C.n << "];\n        }\n    }\n";
+        }
+    }
     // ---- syndrome over the decided bits (src/LDPC_Code_LUT.cpp:455-469): bits exchanged through M[s * E + node]
     o << "    auto put_hard = [&]() {\n";
     for (auto &it : items) o << "        if (ma" << it.sfx << " >= 0) M[sv" << it.sfx << "() * E + nd" << it.sfx << "()] = hard" << it.sfx << ";\n";
@@ -369,7 +386,35 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
     o << "    auto cn_pass = [&](int ii, bool chk) {\n        const uint32_t nz = (uint32_t)kNz[ii];\n        (void)nz;\n";
     if (R.min_lut) {
         o << "        const int sbit = __builtin_ctz(nz);\n        const uint32_t SB = nz * ONE, LOW = SB - ONE;\n";
+        for (auto &ci : citems) {                  // (cn_persistent: every check item of this thread, addresses in registers)
+            const ResidentClass &C = R.ccls[ci.c];
+            o << "        if (cs" << ci.sfx << " >= 0) {\n            const int s = cs" << ci.sfx << ";\n            const uint32_t a = L_act[s];\n            if (a) {\n"
+              << "                const uint32_t am = res_mask<PACK>(a);\n";
+            if (C.deg <= 16) {
+                o << "                uint32_t x[" << C.deg << "], r[" << C.deg << "];\n"
+                  << "#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) x[k] = M[ce" << ci.sfx << "[k]];\n"
+                  << "                const uint32_t tn = res_minsum<" << C.deg << ", PACK>(x, r, sbit, SB, LOW);\n"
+                  << "                if (chk) flag(s, (tn >> sbit) & a);\n"
+                  << "#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) M[ce" << ci.sfx << "[k]] = bfi(am, r[k], x[k]);\n";
+            } else {      // wide checks: two sweeps over LDS, the addresses stay in registers
+                o << "                uint32_t min1 = LOW, min2 = LOW, spp = 0u;\n#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
+                  << "                    spp ^= xh;\n                    const uint32_t g1 = ((mag | SB) - min1) & SB, k1 = g1 - (g1 >> sbit);\n"
+                  << "                    const uint32_t lo = bfi(k1, min1, mag), hi = mag ^ min1 ^ lo;\n"
+                  << "                    const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
+                  << "                    min2 = k == 0 ? LOW : bfi(k2, hi, min2);\n                    min1 = k == 0 ? mag : lo;\n                }\n"
+                  << "                const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
+                  << "                if (chk) flag(s, (tn >> sbit) & a);\n"
+                  << "                const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
+                  << "                    const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
+                  << "                    const uint32_t mc = bfi(ke, m2c, m1c), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
+                  << "                    M[ce" << ci.sfx << "[k]] = bfi(am, (mc ^ kp) | po, xh);\n                }\n";
+            }
+            o << "            }\n        }\n";
+        }
         for (size_t c : corder) {
+            if (!citems.empty()) break;
             const ResidentClass &C = R.ccls[c];
             if (C.deg < 2) { err = "check of degree 1"; return false; }
             o << "        " << cn_loop(c)
