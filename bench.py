@@ -106,6 +106,12 @@ def make_labels_device(cd, B, snr_db, seed, qcha_map=None):
         c = torch.bucketize(llr, qc, right=False)            # number of boundaries strictly below the value (src/common.cpp:120-129)
         cha[b0:b0 + n] = c.to(torch.uint8)
         msg[b0:b0 + n] = torch.bucketize(llr, qm, right=False).to(torch.uint8) if qmap is None else qmap[c]
+    # The decoder runs on its OWN (non-blocking) HIP stream: the labels must be complete, and torch must be done with the temporaries
+    # it has already handed back to its caching allocator, before anything on that stream touches memory torch may reuse -- a
+    # decode started here without this wait reads half-written labels, and its output buffer (a fresh torch.empty) can land on the
+    # freed `llr` block while torch's kernels still read it.
+    del llr, c
+    torch.cuda.synchronize()
     return cha, msg
 
 
@@ -645,7 +651,10 @@ def main():
 
         def step_s(sync):
             dec.lut_decode_batch_device(cha_s.data_ptr(), msg_s.data_ptr(), B, bits_s.data_ptr(), it_s.data_ptr(), sync=sync)
+        torch.cuda.synchronize()                               # the labels are written on torch's stream, the decoder runs on its own
         step_s(True); step_s(True)
+        if os.environ.get("BENCH_DEBUG"):
+            print("debug as_shipped warm", float(it_s.abs().float().mean().item()), int((it_s < 0).sum().item()), int(cha_s.sum(dtype=torch.int64).item()), int(msg_s.sum(dtype=torch.int64).item()), file=sys.stderr)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(args.as_shipped_steps):

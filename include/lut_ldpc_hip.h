@@ -89,7 +89,11 @@ int lutldpc_decoder_decode_batch(lutldpc_decoder *d, const uint8_t *cha, const u
                                  uint8_t *out_bits, int32_t *out_iters);
 
 /* Same with device-resident buffers (same frame-major layout); asynchronous on the decoder's
- * stream unless `sync` is non-zero. */
+ * stream unless `sync` is non-zero.  The call runs on the decoder's OWN non-blocking stream (lutldpc_decoder_stream): the input
+ * buffers must be complete, and the four buffers must not be memory that another stream is still working on (a stream-ordered
+ * allocator may hand out a block whose last users have not finished on THEIR stream) -- synchronise, or make the decoder's
+ * stream wait on an event, before the call.  The inputs are read for the whole duration of the decode (the LDS-resident
+ * decoder reads them in place), the outputs are written by it. */
 int lutldpc_decoder_decode_batch_device(lutldpc_decoder *d, const uint8_t *d_cha, const uint8_t *d_msg0, int B,
                                         uint8_t *d_out_bits, int32_t *d_out_iters, int sync);
 

@@ -28,7 +28,7 @@ def run(wl, B, resident, env=None):
         snr = -10 * np.log10(2 * cd.rate * sigma * sigma) + (0.4 if psc else 0.0)
         cd.set_exit_conditions(max_iter, psc, psc)
         dec = cd.decoder()
-        cha, msg = bench.make_labels_device(cd, B, snr, seed=1234, qcha_map=qmap)
+        cha, msg = bench.make_labels_device(cd, B, snr, seed=1234, qcha_map=qmap)      # (synchronises: the decoder runs on its own stream)
         ob = torch.empty((B, cd.nvar), dtype=torch.uint8, device="cuda"); oi = torch.empty(B, dtype=torch.int32, device="cuda")
         t0 = time.perf_counter()
         for _ in range(3):
