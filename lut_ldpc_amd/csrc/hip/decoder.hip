@@ -1325,7 +1325,7 @@ ResidentSpec resident_spec(const lutldpc_decoder *d, int S, int NT) {
         // (... or the wide trees have cost the occupancy already: N=500 runs two waves per SIMD with 159 registers, +3 % with them;
         // (6,32) N=2048 would fall from three workgroups per compute unit to two: 25.6 -> 23.5 M, off)
         R.cn_persistent = d->resident_cn_persistent >= 0 ? d->resident_cn_persistent
-                          : (d->min_lut && max_cn <= 16 && ((max_vn <= 4 && cn_regs <= 40) || (max_vn > 12 && cn_regs <= 96)) ? 1 : 0);      // (measured: (3,6) N=10000 1.82 -> 1.94 M codewords/s fixed work, 3.7 -> 7.5 M as shipped)
+                          : (d->min_lut && max_cn <= 16 && ((max_vn <= 4 && cn_regs <= 40) || (max_vn > 12 && cn_regs <= 96)) ? 1 : 0);      // (measured: (3,6) N=10000 1.82 -> 1.92 M codewords/s fixed work, 3.65 -> 3.93 M as shipped)
     }
     for (size_t i = 0; i < d->vclass.size(); i++) R.vcls.push_back({d->vclass[i].deg, (int)d->vclass[i].nodes.size(), d->vn_tidx_off[i], 0});
     for (size_t i = 0; i < d->cclass.size(); i++) R.ccls.push_back({d->cclass[i].deg, (int)d->cclass[i].nodes.size(), d->cn_tidx_off[i], d->cn_tnidx_off[i]});
