@@ -104,7 +104,8 @@ __device__ __forceinline__ uint32_t swar_zero_mask(uint32_t x) {
     return z * 0xFFu;
 }
 // (a & m) | (b & ~m)
-__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+// (one v_bitop3_b32 / v_bfi_b32; written out, the compiler hoists ~m of a loop-invariant mask and then needs two instructions per use)
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, (0xCC & 0xF0) | (0xAA & 0x0F)); }
 
 // Row access through a buffer resource: the descriptor (4 SGPRs) covers the rows of one frame group,
 // the row offset is wave-uniform (SGPR soffset) and the lane supplies only its byte offset within the
@@ -221,6 +222,16 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t x, int s, uint32_t y) {
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(y));
     return r;
 }
+
+// (a ^ b) + c in one instruction (the compiler splits it whenever a ^ b has a second use)
+__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+// three-input bit operations of gfx950 (v_bitop3_b32; truth tables from a = 0xF0, b = 0xCC, c = 0xAA)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF0 ^ 0xCC ^ 0xAA); }
+__device__ __forceinline__ uint32_t xor_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, (0xF0 ^ 0xCC) | 0xAA); }   // (a ^ b) | c
 
 #ifndef __HIPCC_RTC__
 // Every kernel of the library is launched through this wrapper: its argument segment stays within 128 bytes -- pointers and a few

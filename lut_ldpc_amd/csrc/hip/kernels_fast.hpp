@@ -43,6 +43,7 @@ namespace lutldpc {
 // FIRST (the check pass of iteration 0 in the fused pipeline): every edge still carries its variable node's initial message
 // (src/LDPC_Code_LUT.cpp:284-289), so the inputs are read from the N initial-message rows through a second table holding the
 // NODE of every check edge -- the E edge rows are written for the first time by this pass, no separate copy kernel.
+constexpr int kCnAllButOneMaxDeg = 16;     // checks up to this degree: all-but-one minima from prefix / suffix minima (registers: DEG - 2 suffixes)
 template <int DEG, int UNR, int PACK, bool CHAIN, typename PT, bool FIRST = false>
 __device__ __forceinline__ void cn_minsum_body(
     const PT &P, int block, uint8_t *msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
@@ -125,8 +126,52 @@ __device__ __forceinline__ void cn_minsum_body(
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (i + u >= last) break;
-            // input sweep: magnitudes, running two smallest, sign parity.  The first two edges need no
-            // comparison against the initial values (after them min1 <= min2 are simply the sorted pair).
+            uint32_t r[DEG];
+            uint32_t tn;
+            if constexpr (DEG <= kCnAllButOneMaxDeg) {
+            // The extrinsic magnitude of an edge, `mag == min1 ? min2 : min1` (src/LDPC_Code_LUT.cpp:376-396), IS the minimum over the
+            // OTHER edges of the check.  All DEG of them come out of suffix minima, a running prefix minimum and one combination
+            // per inner edge -- 3 (DEG - 2) two-input minima, the least any scheme needs -- instead of two compare-selects per edge on
+            // the way in plus an equality test and a select per edge on the way out: 135 instead of 215 vector instructions for a
+            // degree-7 check (eight frames).  Everything runs on COMPLEMENTED magnitudes (nz-1-|.|: a negative label's low bits as
+            // they are), so the minima are maxima and the sign step at the end stays one three-input bit operation.
+            // max: (b ^ LOW) + a carries into bit sbit <=> a > b (one v_xad_u32; fields never overflow: a + (LOW - b) <= 2 LOW)
+            auto mx = [&](uint32_t a, uint32_t b) -> uint32_t {
+                const uint32_t gt = xad(b, LOW, a) & SB;
+                return bfi(gt - (gt >> sbit), a, b);
+            };
+            uint32_t mcs[DEG], spp = 0;
+#pragma unroll
+            for (int k = 0; k < DEG; k++) {
+                const uint32_t xh = x[u][k];
+                const uint32_t pos = xh & SB;
+                mcs[k] = (xh ^ (pos - (pos >> sbit))) & LOW;                  // positive: LOW - magnitude code; negative: the code itself
+                if (k & 1) spp = xor3(spp, x[u][k - 1], xh);                  // sign bits add up in bit sbit (masked below)
+                else if (k == DEG - 1) spp ^= xh;
+            }
+            tn = (spp ^ odd) & SB;                                            // parity of the negative inputs (bit sbit)
+            uint32_t oc[DEG];
+            if constexpr (DEG == 2) { oc[0] = mcs[1]; oc[1] = mcs[0]; }
+            else {
+                uint32_t suf[DEG];
+                suf[DEG - 1] = mcs[DEG - 1];
+#pragma unroll
+                for (int k = DEG - 2; k >= 1; k--) suf[k] = mx(mcs[k], suf[k + 1]);
+                uint32_t pre = mcs[0];
+                oc[0] = suf[1];
+#pragma unroll
+                for (int k = 1; k <= DEG - 2; k++) { oc[k] = mx(pre, suf[k + 1]); pre = mx(pre, mcs[k]); }
+                oc[DEG - 1] = pre;
+            }
+#pragma unroll
+            for (int k = 0; k < DEG; k++) {
+                const uint32_t po = (tn ^ x[u][k]) & SB;                      // extrinsic sign: positive flag
+                const uint32_t kp = po - (po >> sbit);                        // LOW where positive
+                r[k] = xor_or(oc[k], kp, po);                                 // positive nz+m = ((m^LOW)^LOW)|SB, negative nz-1-m = m^LOW
+            }
+            } else {
+            // wide checks: the suffix array would not fit the registers.  Input sweep: magnitudes, running two smallest, sign
+            // parity.  The first two edges need no comparison against the initial values (after them min1 <= min2 are simply the sorted pair).
             uint32_t min1 = LOW, min2 = LOW, spp = 0;
             uint32_t mg[DEG];
 #pragma unroll
@@ -154,12 +199,10 @@ __device__ __forceinline__ void cn_minsum_body(
                     min1 = lo;
                 }
             }
-            const uint32_t tn = (spp ^ odd) & SB;                             // parity of the negative inputs (bit sbit)
-            if (P.check) failw |= tn >> sbit;
+            tn = (spp ^ odd) & SB;                                            // parity of the negative inputs (bit sbit)
             // output sweep: magnitude = (mag == min1 ? min2 : min1), selected directly in complemented form
             // (x ^ LOW = nz-1-x), so that the sign step is one op: positive nz+m = ((m^LOW)^LOW)|SB, negative nz-1-m = m^LOW
             const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;
-            uint32_t r[DEG];
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
                 const uint32_t eq = ~(((mg[k] ^ min1) | SB) - ONE) & SB;      // this edge holds the minimum
@@ -169,6 +212,8 @@ __device__ __forceinline__ void cn_minsum_body(
                 const uint32_t kp = po - (po >> sbit);                        // LOW where positive
                 r[k] = (mc ^ kp) | po;
             }
+            }
+            if (P.check) failw |= tn >> sbit;
             if constexpr (CHAIN) {
                 constexpr int F = 4 * PACK, BITS = 8 / PACK;
                 if (lb && CH.hard) {
@@ -179,6 +224,25 @@ __device__ __forceinline__ void cn_minsum_body(
                 }
                 if (lb && CH.on) {       // wave-uniform: the node shared with the previous check
                     uint32_t o_prev = 0, o_this = 0, dif = 0;
+                    // src/LUT_Tree.cpp:774-790 for two inputs: the message to one check is ROOT(message from the other, channel)
+                    if constexpr (PACK == 2) {
+                        // the table labels (message | channel << shift, below 256) of four frames are formed at once, one per byte --
+                        // low nibbles of the rows = frames 0..3, high nibbles = frames 4..7 -- and a frame costs one extraction
+                        // per look-up instead of three extractions and two merges for its two look-ups
+                        constexpr uint32_t NIB = 0x0F0F0F0Fu;
+                        const uint32_t c_lo = xc & NIB, c_hi = (xc >> 4) & NIB;
+                        const uint32_t ia_lo = lshl_or(c_lo, CH.tab_shift, pend & NIB), ia_hi = lshl_or(c_hi, CH.tab_shift, (pend >> 4) & NIB);
+                        const uint32_t ib_lo = lshl_or(c_lo, CH.tab_shift, r[0] & NIB), ib_hi = lshl_or(c_hi, CH.tab_shift, (r[0] >> 4) & NIB);
+#pragma unroll 1
+                        for (int s = 0; s < 32; s += 8) {          // byte s / 8 of the label words: frames s / 8 and 4 + s / 8
+                            const uint32_t vp0 = lds_tab[__builtin_amdgcn_ubfe(ib_lo, (uint32_t)s, 8u)], vt0 = lds_tab[__builtin_amdgcn_ubfe(ia_lo, (uint32_t)s, 8u)];
+                            const uint32_t vp1 = lds_tab[__builtin_amdgcn_ubfe(ib_hi, (uint32_t)s, 8u)], vt1 = lds_tab[__builtin_amdgcn_ubfe(ia_hi, (uint32_t)s, 8u)];
+                            o_prev = lshl_or(vp0, s, o_prev);
+                            o_this = lshl_or(vt0, s, o_this);
+                            o_prev = lshl_or(vp1, s + 4, o_prev);
+                            o_this = lshl_or(vt1, s + 4, o_this);
+                        }
+                    } else {
 #pragma unroll 1
                     for (int s = 0; s < F * BITS; s += 2 * BITS) {
 #pragma unroll
@@ -186,15 +250,15 @@ __device__ __forceinline__ void cn_minsum_body(
                             const int sb = s + t * BITS;
                             const uint32_t a = __builtin_amdgcn_ubfe(pend, (uint32_t)sb, (uint32_t)BITS), b = __builtin_amdgcn_ubfe(r[0], (uint32_t)sb, (uint32_t)BITS);
                             const uint32_t c = __builtin_amdgcn_ubfe(xc, (uint32_t)sb, (uint32_t)BITS);
-                            // src/LUT_Tree.cpp:774-790 for two inputs: the message to one check is ROOT(message from the other, channel)
                             const uint32_t vp = lds_tab[lshl_or(c, CH.tab_shift, b)], vt = lds_tab[lshl_or(c, CH.tab_shift, a)];
                             o_prev = lshl_or(vp, sb, o_prev);
                             o_this = lshl_or(vt, sb, o_this);
                         }
                     }
+                    }
                     if (CH.check) dif = ((o_prev ^ o_this) >> CH.sbit_out) & ONE;    // the two outgoing signs differ (all frames of the dword at once)
                     chainfail |= dif;
-                    st_row(base, (uint32_t)pend_e * kRowBytes, lane4, bfi(smask, o_prev, pend_old));
+                    st_row(base, (uint32_t)__builtin_amdgcn_readfirstlane(pend_e) * kRowBytes, lane4, bfi(smask, o_prev, pend_old));      // (wave-uniform: keeps the row offset scalar)
                     r[0] = o_this;
                 }
                 if (lf && CH.on) { pend = r[1]; pend_e = e[u][1]; pend_old = x[u][1]; }
