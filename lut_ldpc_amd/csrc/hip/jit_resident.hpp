@@ -397,19 +397,19 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "                if (chk) flag(s, (tn >> sbit) & a);\n"
                   << "#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) M[ce" << ci.sfx << "[k]] = bfi(am, r[k], x[k]);\n";
             } else {      // wide checks: two sweeps over LDS, the addresses stay in registers
-                o << "                uint32_t min1 = LOW, min2 = LOW, spp = 0u;\n#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
-                  << "                    spp ^= xh;\n                    const uint32_t g1 = ((mag | SB) - min1) & SB, k1 = g1 - (g1 >> sbit);\n"
-                  << "                    const uint32_t lo = bfi(k1, min1, mag), hi = mag ^ min1 ^ lo;\n"
-                  << "                    const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
-                  << "                    min2 = k == 0 ? LOW : bfi(k2, hi, min2);\n                    min1 = k == 0 ? mag : lo;\n                }\n"
+                o << "                uint32_t max1 = 0u, max2 = 0u, spp = 0u;      // the two LARGEST complemented magnitudes = the two smallest magnitudes\n#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, mc = (xh ^ (pos - (pos >> sbit))) & LOW;\n"
+                  << "                    spp ^= xh;\n                    const uint32_t g1 = xad(max1, LOW, mc) & SB, k1 = g1 - (g1 >> sbit);      // mc > max1\n"
+                  << "                    const uint32_t hi = bfi(k1, mc, max1), lo = xor3(mc, max1, hi);\n"
+                  << "                    const uint32_t g2 = xad(max2, LOW, lo) & SB, k2 = g2 - (g2 >> sbit);\n"
+                  << "                    max2 = bfi(k2, lo, max2);\n                    max1 = hi;\n                }\n"
                   << "                const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
                   << "                if (chk) flag(s, (tn >> sbit) & a);\n"
-                  << "                const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
-                  << "                    const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
-                  << "                    const uint32_t mc = bfi(ke, m2c, m1c), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
-                  << "                    M[ce" << ci.sfx << "[k]] = bfi(am, (mc ^ kp) | po, xh);\n                }\n";
+                  << "#pragma unroll\n                for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                    const uint32_t xh = M[ce" << ci.sfx << "[k]];\n                    const uint32_t pos = xh & SB, mc = (xh ^ (pos - (pos >> sbit))) & LOW;\n"
+                  << "                    const uint32_t eq = ~(((mc ^ max1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
+                  << "                    const uint32_t sel = bfi(ke, max2, max1), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
+                  << "                    M[ce" << ci.sfx << "[k]] = bfi(am, xor_or(sel, kp, po), xh);\n                }\n";
             }
             o << "            }\n        }\n";
         }
@@ -430,19 +430,19 @@ inline bool jit_resident_source(const ResidentSpec &R, std::string &src, std::st
                   << "#pragma unroll\n            for (int k = 0; k < " << C.deg << "; k++) Ms[e[k]] = bfi(am, r[k], x[k]);\n";
             } else {
                 // wide checks: two sweeps over the check's edges (the messages are re-read from LDS instead of held in registers)
-                o << "            uint32_t min1 = LOW, min2 = LOW, spp = 0u;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                const uint32_t xh = Ms[ed[k * ES]];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
-                  << "                spp ^= xh;\n                const uint32_t g1 = ((mag | SB) - min1) & SB, k1 = g1 - (g1 >> sbit);\n"
-                  << "                const uint32_t lo = bfi(k1, min1, mag), hi = mag ^ min1 ^ lo;\n"
-                  << "                const uint32_t g2 = ((min2 | SB) - hi) & SB, k2 = g2 - (g2 >> sbit);\n"
-                  << "                min2 = k == 0 ? LOW : bfi(k2, hi, min2);\n                min1 = k == 0 ? mag : lo;\n            }\n"
+                o << "            uint32_t max1 = 0u, max2 = 0u, spp = 0u;      // the two LARGEST complemented magnitudes = the two smallest magnitudes\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                const uint32_t xh = Ms[ed[k * ES]];\n                const uint32_t pos = xh & SB, mc = (xh ^ (pos - (pos >> sbit))) & LOW;\n"
+                  << "                spp ^= xh;\n                const uint32_t g1 = xad(max1, LOW, mc) & SB, k1 = g1 - (g1 >> sbit);      // mc > max1\n"
+                  << "                const uint32_t hi = bfi(k1, mc, max1), lo = xor3(mc, max1, hi);\n"
+                  << "                const uint32_t g2 = xad(max2, LOW, lo) & SB, k2 = g2 - (g2 >> sbit);\n"
+                  << "                max2 = bfi(k2, lo, max2);\n                max1 = hi;\n            }\n"
                   << "            const uint32_t tn = (spp ^ " << ((C.deg & 1) ? "SB" : "0u") << ") & SB;\n"
                   << "            if (chk) flag(s, (tn >> sbit) & a);\n"
-                  << "            const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;\n#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
-                  << "                const int ek = ed[k * ES];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, pm = pos - (pos >> sbit), mag = (xh ^ pm ^ LOW) & LOW;\n"
-                  << "                const uint32_t eq = ~(((mag ^ min1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
-                  << "                const uint32_t mc = bfi(ke, m2c, m1c), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
-                  << "                Ms[ek] = bfi(am, (mc ^ kp) | po, xh);\n            }\n";
+                  << "#pragma unroll 4\n            for (int k = 0; k < " << C.deg << "; k++) {\n"
+                  << "                const int ek = ed[k * ES];\n                const uint32_t xh = Ms[ek];\n                const uint32_t pos = xh & SB, mc = (xh ^ (pos - (pos >> sbit))) & LOW;\n"
+                  << "                const uint32_t eq = ~(((mc ^ max1) | SB) - ONE) & SB, ke = eq - (eq >> sbit);\n"
+                  << "                const uint32_t sel = bfi(ke, max2, max1), po = (tn ^ xh) & SB, kp = po - (po >> sbit);\n"
+                  << "                Ms[ek] = bfi(am, xor_or(sel, kp, po), xh);\n            }\n";
             }
             o << "        }\n";
         }

@@ -14,50 +14,48 @@
 namespace lutldpc {
 
 // Min-sum check update on the packed labels of one check (src/LDPC_Code_LUT.cpp:355-402): x[k] = dword of edge k (8 nibble
-// frames / 4 byte frames), r[k] = extrinsic output.  Same arithmetic as cn_minsum_body (kernels_fast.hpp): sign bit `sbit`
-// doubles as the flag bit of every comparison, min1 / min2 running, output magnitude = (mag == min1 ? min2 : min1).
+// frames / 4 byte frames), r[k] = extrinsic output.  Same arithmetic as cn_minsum_body (kernels_fast.hpp): the extrinsic
+// magnitude `mag == min1 ? min2 : min1` is the minimum over the OTHER edges, and all DEG of them come out of suffix minima,
+// a running prefix minimum and one combination per inner edge -- 3 (DEG - 2) two-input minima -- on complemented magnitudes
+// (minima become maxima, the sign step stays one three-input bit operation); sign bit `sbit` is the flag bit of every comparison.
 // Returns the parity of the negative inputs in bit `sbit` of every element (the check's syndrome bit per frame).
 template <int DEG, int PACK>
 __device__ __forceinline__ uint32_t res_minsum(const uint32_t (&x)[DEG], uint32_t (&r)[DEG], int sbit, uint32_t SB, uint32_t LOW) {
-    constexpr uint32_t ONE = PACK == 2 ? 0x11111111u : 0x01010101u;
     const uint32_t odd = (DEG & 1) ? SB : 0u;
-    uint32_t min1 = LOW, min2 = LOW, spp = 0;
-    uint32_t mg[DEG];
+    // max of two complemented magnitudes: (b ^ LOW) + a carries into bit sbit <=> a > b
+    auto mx = [&](uint32_t a, uint32_t b) -> uint32_t {
+        const uint32_t gt = xad(b, LOW, a) & SB;
+        return bfi(gt - (gt >> sbit), a, b);
+    };
+    uint32_t mcs[DEG], spp = 0;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         const uint32_t xh = x[k];
         const uint32_t pos = xh & SB;
-        const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
-        const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
-        spp ^= xh;
-        mg[k] = mag;
-        if (k == 0) {
-            min1 = mag;
-        } else {
-            const uint32_t g1 = ((mag | SB) - min1) & SB;         // mag >= min1
-            const uint32_t k1 = g1 - (g1 >> sbit);
-            const uint32_t lo = bfi(k1, min1, mag);
-            const uint32_t hi = mag ^ min1 ^ lo;
-            if (k == 1) {
-                min2 = hi;
-            } else {
-                const uint32_t g2 = ((min2 | SB) - hi) & SB;      // min2 >= hi
-                const uint32_t k2 = g2 - (g2 >> sbit);
-                min2 = bfi(k2, hi, min2);
-            }
-            min1 = lo;
-        }
+        mcs[k] = (xh ^ (pos - (pos >> sbit))) & LOW;              // positive: LOW - magnitude code; negative: the code itself
+        if (k & 1) spp = xor3(spp, x[k - 1], xh);
+        else if (k == DEG - 1) spp ^= xh;
     }
     const uint32_t tn = (spp ^ odd) & SB;
-    const uint32_t m1c = min1 ^ LOW, m2c = min2 ^ LOW;
+    uint32_t oc[DEG];
+    if constexpr (DEG == 1) oc[0] = 0u;                           // (no other edge: magnitude nz-1, as min1 = LOW gave before)
+    else if constexpr (DEG == 2) { oc[0] = mcs[1]; oc[1] = mcs[0]; }
+    else {
+        uint32_t suf[DEG];
+        suf[DEG - 1] = mcs[DEG - 1];
+#pragma unroll
+        for (int k = DEG - 2; k >= 1; k--) suf[k] = mx(mcs[k], suf[k + 1]);
+        uint32_t pre = mcs[0];
+        oc[0] = suf[1];
+#pragma unroll
+        for (int k = 1; k <= DEG - 2; k++) { oc[k] = mx(pre, suf[k + 1]); pre = mx(pre, mcs[k]); }
+        oc[DEG - 1] = pre;
+    }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const uint32_t eq = ~(((mg[k] ^ min1) | SB) - ONE) & SB;
-        const uint32_t ke = eq - (eq >> sbit);
-        const uint32_t mc = bfi(ke, m2c, m1c);
         const uint32_t po = (tn ^ x[k]) & SB;
         const uint32_t kp = po - (po >> sbit);
-        r[k] = (mc ^ kp) | po;
+        r[k] = xor_or(oc[k], kp, po);
     }
     return tn;
 }
