@@ -90,6 +90,11 @@ struct lutldpc_decoder {
     TreeArray var_trees, chk_trees;
     // ---- programs: [set][class]
     std::vector<std::vector<Program>> var_prog, chk_prog, dec_prog;
+    // check programs over full labels (lut_program.hpp: chk_full_label_program) for the generated check kernels, and where their
+    // tables sit in the blob: [set][class], {offset, bytes}, bytes = 0: none (the generated kernel then works on sign / magnitude)
+    std::vector<std::vector<Program>> chk_prog_full;
+    std::vector<std::vector<std::pair<int, int>>> chk_full_tab;
+    int chk_full_labels = 1;    // LUTLDPC_CHK_FULL=0: generated check kernels on (sign, magnitude) tables as the reference walks them
     // the same trees after exact table composition (lut_program.hpp: compose_tree): fewer, larger look-ups; used by the generated
     // LDS-resident kernel.  *_tab_c: {offset, bytes} of the class blob inside all_tables.  LUTLDPC_COMPOSE=0: off (the originals).
     std::vector<std::vector<Program>> var_prog_c, chk_prog_c, dec_prog_c;
@@ -563,6 +568,7 @@ int compile_all(lutldpc_decoder *d) {
     d->var_prog.assign(ns, {}); d->dec_prog.assign(ns, {}); d->chk_prog.assign(ns, {});
     d->var_plan.assign(ns, {}); d->dec_plan.assign(ns, {}); d->chk_plan.assign(ns, {});
     d->var_fast.assign(ns, {}); d->dec_fast.assign(ns, {});
+    d->chk_prog_full.assign(ns, {}); d->chk_full_tab.assign(ns, {});
     d->var_prog_c.assign(ns, {}); d->dec_prog_c.assign(ns, {}); d->chk_prog_c.assign(ns, {});
     d->var_tab_c.assign(ns, {}); d->dec_tab_c.assign(ns, {}); d->chk_tab_c.assign(ns, {});
     for (size_t s = 0; s < ns; s++) {
@@ -572,7 +578,20 @@ int compile_all(lutldpc_decoder *d) {
         if (type == TT_DEC) rc = add_set(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog[s], d->dec_plan[s], &d->dec_fast[s]);
         else rc = add_set(d->var_trees[s], d->vclass, TT_VAR, d->var_prog[s], d->var_plan[s], &d->var_fast[s]);
         if (rc) return rc;
-        if (!d->min_lut) { rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s], nullptr); if (rc) return rc; }
+        if (!d->min_lut) {
+            rc = add_set(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog[s], d->chk_plan[s], nullptr);
+            if (rc) return rc;
+            d->chk_prog_full[s].assign(d->cclass.size(), Program());
+            d->chk_full_tab[s].assign(d->cclass.size(), {0, 0});
+            for (size_t i = 0; i < d->cclass.size() && d->chk_full_labels; i++) {
+                Program f;
+                if (!chk_full_label_program(d->chk_prog[s][i], f) || f.tables.empty()) continue;
+                while (d->all_tables.size() & 15) d->all_tables.push_back(0);
+                d->chk_full_tab[s][i] = {(int)d->all_tables.size(), (int)f.tables.size()};
+                d->all_tables.insert(d->all_tables.end(), f.tables.begin(), f.tables.end());
+                d->chk_prog_full[s][i] = std::move(f);
+            }
+        }
         if (type == TT_DEC) rc = add_composed(d->var_trees[s], d->vclass, TT_DEC, d->dec_prog_c[s], d->dec_tab_c[s]);
         else rc = add_composed(d->var_trees[s], d->vclass, TT_VAR, d->var_prog_c[s], d->var_tab_c[s]);
         if (rc) return rc;
@@ -636,7 +655,9 @@ void build_jit(lutldpc_decoder *d) {
             for (size_t i = 0; i < cls.size(); i++) {
                 if (kind != TT_CHK && fast_covers(d, kind == TT_VAR ? d->var_fast[s] : d->dec_fast[s], i)) continue;
                 std::string src, err;
-                const bool gen = kind == TT_CHK ? jit_cn_source(progs[i], cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err)
+                const bool full = kind == TT_CHK && s < d->chk_full_tab.size() && i < d->chk_full_tab[s].size() && d->chk_full_tab[s][i].second > 0;
+                const bool gen = kind == TT_CHK ? (full ? jit_cn_source(d->chk_prog_full[s][i], cls[i].deg, d->pack, d->chk_full_tab[s][i].second, src, err)
+                                                        : jit_cn_source(progs[i], cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err))
                                                 : jit_vn_source(progs[i], kind, cls[i].deg, d->pack, plan.P.seg[i].tab_bytes, src, err);
                 if (!gen) { d->jit_log = err; continue; }
                 JitRegistry &reg = jit_registry();
@@ -867,7 +888,8 @@ PassParams filter_params(const PassParams &P, const std::vector<char> &keep) {
 }
 
 template <int KIND>
-int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPlan> *fast, const std::vector<const JitKernel *> *jit, int G, int nz, int check, int write_hard, int kind_id) {
+int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPlan> *fast, const std::vector<const JitKernel *> *jit, int G, int nz, int check, int write_hard, int kind_id,
+                     const std::vector<std::pair<int, int>> *jit_tabs = nullptr) {
     if (!plan.valid) return fail(LUTLDPC_ERR_STATE, "pass plan missing for this tree set");
     Timed t(d, kind_id);
     PassParams P = plan.P;
@@ -897,6 +919,7 @@ int launch_tree_pass(lutldpc_decoder *d, PassPlan &plan, std::vector<FastClassPl
             F.nodes_per_wave = KIND == TT_CHK ? d->npw_cn(F.deg) : d->npw_vn(F.deg); F.waves_per_group = (F.n_nodes + F.nodes_per_wave - 1) / F.nodes_per_wave;
             F.G = G; F.E = d->E; F.N = d->nvar; F.g0 = 0; F.nz = nz; F.check = check; F.write_hard = write_hard; F.vfail_stride_w = d->Bcap / 4;
             F.tab_off[0] = P.seg[i].tab_off; F.tab_len[0] = P.seg[i].tab_bytes;
+            if (jit_tabs && (size_t)i < jit_tabs->size() && (*jit_tabs)[(size_t)i].second > 0) { F.tab_off[0] = (*jit_tabs)[(size_t)i].first; F.tab_len[0] = (*jit_tabs)[(size_t)i].second; }   // the kernel was generated for these tables
             uint8_t *msgs = d->d_msgs.p, *hard = d->d_hard.p;
             const uint8_t *cha = d->d_cha_t.p, *tables = d->d_tables.p;
             const uint32_t *state_w = reinterpret_cast<const uint32_t *>(d->d_state.p);
@@ -1508,7 +1531,8 @@ int decode_tiles_launch(lutldpc_decoder *d, int B) {
         const int nz_in = d->Nq_Msg[(size_t)ii] / 2;
         const int chk_check = (d->psc && ii > 0) ? 1 : 0;    // finishes the test started by VN pass ii-1
         if (d->min_lut) rc = launch_cn_minsum(d, G, nz_in, chk_check);
-        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, d->chk_jit.empty() ? nullptr : &d->chk_jit[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS);
+        else rc = launch_tree_pass<TT_CHK>(d, d->chk_plan[(size_t)set], nullptr, d->chk_jit.empty() ? nullptr : &d->chk_jit[(size_t)set], G, nz_in, chk_check, 0, LUTLDPC_K_CN_PASS,
+                                           (size_t)set < d->chk_full_tab.size() ? &d->chk_full_tab[(size_t)set] : nullptr);
         if (rc) return rc;
         if (chk_check && (rc = launch_state(d, B, Bpad, 2, ii))) return rc;   // :327-329 returns (ii-1)+1
         if (d->trace.level > 2 && (rc = trace_dump(d))) return rc;             // :311-317
@@ -1760,6 +1784,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_RESIDENT_WAVES_EU")) { int v = atoi(e); if (v >= 0 && v <= 8) d->resident_waves_eu = v; }
     if (const char *e = getenv("LUTLDPC_RESIDENT_U")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) d->resident_U = v; }
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_CHK_FULL")) d->chk_full_labels = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_KEEP")) d->compact_keep = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }
@@ -1984,7 +2009,12 @@ int64_t lutldpc_decoder_device_bytes(lutldpc_decoder *d) {
 const char *lutldpc_decoder_describe(lutldpc_decoder *d) { return d ? d->describe.c_str() : ""; }
 
 // kind + 16: the program of the same tree after table composition (compose_tree)
+// kind + 32 (checks): the program over full labels the generated check kernels run (chk_full_label_program)
 static const Program *find_prog(lutldpc_decoder *d, int kind, int set, int cls) {
+    if (kind == TT_CHK + 32) {
+        if (set < 0 || set >= (int)d->chk_prog_full.size() || cls < 0 || cls >= (int)d->chk_prog_full[(size_t)set].size() || d->chk_full_tab[(size_t)set][(size_t)cls].second == 0) return nullptr;
+        return &d->chk_prog_full[(size_t)set][(size_t)cls];
+    }
     const bool comp = (kind & 16) != 0;
     kind &= 15;
     auto &v = comp ? (kind == TT_VAR ? d->var_prog_c : kind == TT_CHK ? d->chk_prog_c : d->dec_prog_c) : (kind == TT_VAR ? d->var_prog : kind == TT_CHK ? d->chk_prog : d->dec_prog);

@@ -122,6 +122,19 @@ __device__ __forceinline__ void cn_minsum_body(
             if constexpr (CHAIN) xcn = ld_row(cbase, (uint32_t)(lbn > 0 ? lbn - 1 : 0) * kRowBytes, (i + u < last && lbn > 0 && CH.on) ? lane4 : (lane4 | 0x80000000u));
         }
     };
+    // complemented magnitude (nz-1-|.|) of a stored message, and the stored form of (complemented magnitude, positive flag)
+    // (Storing the messages as [sign | complemented magnitude] instead -- re-labelled root tables on the variable side, one AND here
+    // and one OR on the way out -- saves 7 of these instructions per edge and was measured: slower in both directions (the four hot
+    // table entries of a converged decoder, both operands saturated with either sign, land pairwise 128 bytes apart = on one LDS
+    // bank, where the labels 0 and 2 nz - 1 differ in every bit: DVB-S2 265 -> 248 k codewords/s) and no faster with only the
+    // variable-to-check direction re-labelled (the pass streams at the HBM rate by now: 253.1 against 255.8 k, four interleaved runs).)
+    auto to_mc = [&](uint32_t xh) -> uint32_t {
+        const uint32_t pos = xh & SB;
+        return (xh ^ (pos - (pos >> sbit))) & LOW;           // positive label: LOW - magnitude code; negative: the code itself
+    };
+    auto from_mc = [&](uint32_t mc, uint32_t po) -> uint32_t {
+        return xor_or(mc, po - (po >> sbit), po);            // positive nz+m = ((m^LOW)^LOW)|SB, negative nz-1-m = m^LOW
+    };
     auto eval = [&](int i, const uint32_t (&x)[UNR][DEG], const int (&e)[UNR][DEG]) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
@@ -144,14 +157,14 @@ __device__ __forceinline__ void cn_minsum_body(
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
                 const uint32_t xh = x[u][k];
-                const uint32_t pos = xh & SB;
-                mcs[k] = (xh ^ (pos - (pos >> sbit))) & LOW;                  // positive: LOW - magnitude code; negative: the code itself
+                mcs[k] = to_mc(xh);
                 if (k & 1) spp = xor3(spp, x[u][k - 1], xh);                  // sign bits add up in bit sbit (masked below)
                 else if (k == DEG - 1) spp ^= xh;
             }
             tn = (spp ^ odd) & SB;                                            // parity of the negative inputs (bit sbit)
             uint32_t oc[DEG];
-            if constexpr (DEG == 2) { oc[0] = mcs[1]; oc[1] = mcs[0]; }
+            if constexpr (DEG == 1) oc[0] = 0u;                               // (never launched: fill_cn_fast refuses degree 1)
+            else if constexpr (DEG == 2) { oc[0] = mcs[1]; oc[1] = mcs[0]; }
             else {
                 uint32_t suf[DEG];
                 suf[DEG - 1] = mcs[DEG - 1];
@@ -164,11 +177,7 @@ __device__ __forceinline__ void cn_minsum_body(
                 oc[DEG - 1] = pre;
             }
 #pragma unroll
-            for (int k = 0; k < DEG; k++) {
-                const uint32_t po = (tn ^ x[u][k]) & SB;                      // extrinsic sign: positive flag
-                const uint32_t kp = po - (po >> sbit);                        // LOW where positive
-                r[k] = xor_or(oc[k], kp, po);                                 // positive nz+m = ((m^LOW)^LOW)|SB, negative nz-1-m = m^LOW
-            }
+            for (int k = 0; k < DEG; k++) r[k] = from_mc(oc[k], (tn ^ x[u][k]) & SB);      // extrinsic sign: positive flag
             } else {
             // wide checks: the suffix array would not fit the registers.  Input sweep: magnitudes, running two smallest, sign
             // parity.  The first two edges need no comparison against the initial values (after them min1 <= min2 are simply the sorted pair).
@@ -177,9 +186,7 @@ __device__ __forceinline__ void cn_minsum_body(
 #pragma unroll
             for (int k = 0; k < DEG; k++) {
                 const uint32_t xh = x[u][k];
-                const uint32_t pos = xh & SB;
-                const uint32_t pm = pos - (pos >> sbit);                  // LOW where positive
-                const uint32_t mag = (xh ^ pm ^ LOW) & LOW;
+                const uint32_t mag = to_mc(xh) ^ LOW;
                 spp ^= xh;                                                // sign bits add up in bit sbit (masked below)
                 mg[k] = mag;
                 if (k == 0) {
@@ -207,15 +214,12 @@ __device__ __forceinline__ void cn_minsum_body(
             for (int k = 0; k < DEG; k++) {
                 const uint32_t eq = ~(((mg[k] ^ min1) | SB) - ONE) & SB;      // this edge holds the minimum
                 const uint32_t ke = eq - (eq >> sbit);
-                const uint32_t mc = bfi(ke, m2c, m1c);
-                const uint32_t po = (tn ^ x[u][k]) & SB;                      // extrinsic sign: positive flag
-                const uint32_t kp = po - (po >> sbit);                        // LOW where positive
-                r[k] = (mc ^ kp) | po;
+                r[k] = from_mc(bfi(ke, m2c, m1c), (tn ^ x[u][k]) & SB);       // extrinsic sign: positive flag
             }
             }
             if (P.check) failw |= tn >> sbit;
             if constexpr (CHAIN) {
-                constexpr int F = 4 * PACK, BITS = 8 / PACK;
+                [[maybe_unused]] constexpr int F = 4 * PACK, BITS = 8 / PACK;
                 if (lb && CH.hard) {
                     // decided bit of the node shared with the previous check = sign of the message it sent to this check last
                     // iteration (unanimous whenever the frame passes the exit test, src/LDPC_Code_LUT.cpp:437-452)
@@ -459,7 +463,6 @@ __device__ __forceinline__ void vn_balanced_body(
     uint32_t amask[PACK];
     if (load_active<PACK>(state_w, g, lane, amask)) return;
     const uint32_t smask = pack_masks<PACK>(amask);
-    const bool all_active = __ballot(smask != 0xFFFFFFFFu) == 0ull;      // wave-uniform: no frozen frame, plain stores
     const int32_t *vtab = fast_idx + P.idx_off;                 // dense [n_nodes][2] = {node id, first edge}
     const rsrc_t mbase = make_rsrc(msgs + (size_t)g * (size_t)P.E * kRowBytes, (uint32_t)P.E * kRowBytes);   // this group's rows
     const rsrc_t cbase = make_rsrc(cha + (size_t)g * (size_t)P.N * kRowBytes, (uint32_t)P.N * kRowBytes);
@@ -540,7 +543,7 @@ __device__ __forceinline__ void vn_balanced_body(
             store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         } else {
 #pragma unroll
-            for (int o = 0; o < DV; o++) st_row(mbase, (uint32_t)(e0 + o) * kRowBytes, lane4, all_active ? out[o] : bfi(smask, out[o], raw[o]));
+            for (int o = 0; o < DV; o++) st_row(mbase, (uint32_t)(e0 + o) * kRowBytes, lane4, bfi(smask, out[o], raw[o]));      // (one instruction: cheaper than selecting the plain value for an all-active wave)
             if (CHECK && P.write_hard)
                 store_row_masked<PACK>(reinterpret_cast<uint32_t *>(hbase + (size_t)v * kRowBytes + lane4), hardw, smask);
         }

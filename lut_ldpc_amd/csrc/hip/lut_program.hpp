@@ -452,4 +452,50 @@ inline bool eval_program(const Program &P, const int32_t *in, int32_t *out) {
     return true;
 }
 
+// ---- check-node programs over FULL labels ---------------------------------------------------------------------------
+// The reference's check look-up (src/LUT_Tree.cpp:420-445) works on (sign, magnitude): label = sum of the children's magnitudes
+// times their place values, the parity of the children's signs picks Q[label] or K-1-Q[label].  Evaluated that way a look-up
+// costs nine vector instructions (two splits, label, parity, half select).  The same function of the children's LABELS is one
+// table of prod(K_c) entries -- 64 bytes for two 3-bit children, 256 for two 4-bit ones -- and then a look-up is what a
+// variable-node look-up is: one v_lshl_or_b32 and one ds_read_u8.  Bit-exact by construction (the table is the map itself).
+// out = a copy of `prog` with kind-2 ops (label = sum child * mult over full alphabets) and its own table blob.
+inline bool chk_full_label_program(const Program &prog, Program &out, uint64_t max_entries = 4096) {
+    if (prog.kind != TT_CHK) return false;
+    out = prog;
+    out.tables.clear();
+    out.node_tabs.clear();
+    std::map<std::pair<uint32_t, std::vector<uint16_t>>, uint32_t> done;       // (old table, child alphabets) -> new offset
+    for (auto &op : out.ops) {
+        if (op.kind != 1 || op.nchild < 1) return false;
+        uint64_t space = 1;
+        std::vector<uint16_t> Ks;
+        for (int c = 0; c < op.nchild; c++) { const int K = op.childK[c]; if (K < 2 || (K & 1)) return false; space *= (uint64_t)K; Ks.push_back((uint16_t)K); if (space > max_entries) return false; }
+        const auto key = std::make_pair(op.tab_off, Ks);
+        auto it = done.find(key);
+        if (it == done.end()) {
+            const uint32_t noff = (uint32_t)out.tables.size();
+            out.tables.resize(noff + (size_t)space);
+            std::vector<int> lab((size_t)op.nchild, 0);
+            for (uint64_t i = 0; i < space; i++) {
+                uint64_t r = i, idx = 0; int par = 0;
+                for (int c = 0; c < op.nchild; c++) {
+                    const int K = op.childK[c], hh = K / 2, l = (int)(r % (uint64_t)K);
+                    r /= (uint64_t)K;
+                    const int n = l < hh ? 1 : 0, m = n ? hh - 1 - l : l - hh;
+                    idx += (uint64_t)m * op.mult[c]; par ^= n;
+                }
+                const uint64_t src = (uint64_t)op.tab_off + (par ? 0u : op.half_len) + idx;      // odd sign parity -> first half
+                if (src >= prog.tables.size()) return false;
+                out.tables[noff + (size_t)i] = prog.tables[(size_t)src];
+            }
+            while (out.tables.size() & 3) out.tables.push_back(0);
+            it = done.emplace(key, noff).first;
+        }
+        uint32_t base = 1;
+        for (int c = 0; c < op.nchild; c++) { op.mult[c] = base; base *= (uint32_t)op.childK[c]; }
+        op.kind = 2; op.tab_off = it->second; op.tab_len = (uint32_t)space; op.half_len = 0;
+    }
+    return true;
+}
+
 }  // namespace lutldpc

@@ -151,6 +151,31 @@ def _check_composed(cd, dec, kind, tree_set, cls, deg, n_trials, rng, k_in, k_ch
         assert (want == got).all(), (kind, tree_set, cls, x, want, got)
 
 
+FULL_LABELS = 32   # CHK + 32: the check program over the children's full labels (lut_program.hpp: chk_full_label_program)
+
+
+@pytest.mark.parametrize("name", ["reg36_n1000_q3_chklut", "c5_chklut"])
+def test_full_label_check_programs_match_oracle_tree_walk(name):
+    """The generated check kernels look a CHKTREE node up by its children's LABELS (one table of prod(K) entries, one instruction per
+    look-up) instead of by (sign parity, magnitudes) as src/LUT_Tree.cpp:420-445 walks it: the same map, checked here against the
+    oracle's recursion over the original tree on random inputs, every degree class of every tree set."""
+    cd = oracle_codec(name)
+    dec = product_decoder(cd, device=-1)
+    rng = np.random.default_rng(21)
+    degs_c = sorted(set(cd.code.dc.tolist()))
+    set_iters = np.flatnonzero(np.asarray(cd.reuse_vec) == 0)
+    for s in range(cd.n_sets()):
+        k_in = int(cd.nq_msg[int(set_iters[s])])
+        for cls, dc in enumerate(degs_c):
+            assert dec.program_stats(CHK + FULL_LABELS, s, cls)["ops"] == dec.program_stats(CHK, s, cls)["ops"]
+            for _ in range(60):
+                x = rng.integers(0, k_in, dc).astype(np.int32)
+                want = cd.tree_eval(CHK, s, cls, x, dc)
+                got = dec.program_eval(CHK + FULL_LABELS, s, cls, x, dc)
+                assert (want == got).all(), (s, cls, x, want, got)
+    dec.close()
+
+
 def test_composition_look_up_counts(monkeypatch):
     """Balanced trees: degree 3 -> three 3-input look-ups instead of six; degree 8 -> 20 instead of 34."""
     monkeypatch.setenv("LUTLDPC_COMPOSE", "1")
