@@ -94,6 +94,8 @@ struct lutldpc_decoder {
     // tables sit in the blob: [set][class], {offset, bytes}, bytes = 0: none (the generated kernel then works on sign / magnitude)
     std::vector<std::vector<Program>> chk_prog_full;
     std::vector<std::vector<std::pair<int, int>>> chk_full_tab;
+    std::vector<std::vector<Program>> chk_prog_cf;                    // the same for the programs the LDS-resident decoder runs (chk_prog_c)
+    std::vector<std::vector<std::pair<int, int>>> chk_tab_cf;
     int chk_full_labels = 1;    // LUTLDPC_CHK_FULL=0: generated check kernels on (sign, magnitude) tables as the reference walks them
     // the same trees after exact table composition (lut_program.hpp: compose_tree): fewer, larger look-ups; used by the generated
     // LDS-resident kernel.  *_tab_c: {offset, bytes} of the class blob inside all_tables.  LUTLDPC_COMPOSE=0: off (the originals).
@@ -569,6 +571,7 @@ int compile_all(lutldpc_decoder *d) {
     d->var_plan.assign(ns, {}); d->dec_plan.assign(ns, {}); d->chk_plan.assign(ns, {});
     d->var_fast.assign(ns, {}); d->dec_fast.assign(ns, {});
     d->chk_prog_full.assign(ns, {}); d->chk_full_tab.assign(ns, {});
+    d->chk_prog_cf.assign(ns, {}); d->chk_tab_cf.assign(ns, {});
     d->var_prog_c.assign(ns, {}); d->dec_prog_c.assign(ns, {}); d->chk_prog_c.assign(ns, {});
     d->var_tab_c.assign(ns, {}); d->dec_tab_c.assign(ns, {}); d->chk_tab_c.assign(ns, {});
     for (size_t s = 0; s < ns; s++) {
@@ -596,6 +599,18 @@ int compile_all(lutldpc_decoder *d) {
         else rc = add_composed(d->var_trees[s], d->vclass, TT_VAR, d->var_prog_c[s], d->var_tab_c[s]);
         if (rc) return rc;
         if (!d->min_lut && (rc = add_composed(d->chk_trees[s], d->cclass, TT_CHK, d->chk_prog_c[s], d->chk_tab_c[s]))) return rc;
+        if (!d->min_lut) {
+            d->chk_prog_cf[s].assign(d->cclass.size(), Program());
+            d->chk_tab_cf[s].assign(d->cclass.size(), {0, 0});
+            for (size_t i = 0; i < d->cclass.size() && d->chk_full_labels; i++) {
+                Program f;
+                if (!chk_full_label_program(d->chk_prog_c[s][i], f) || f.tables.empty()) continue;
+                while (d->all_tables.size() & 15) d->all_tables.push_back(0);
+                d->chk_tab_cf[s][i] = {(int)d->all_tables.size(), (int)f.tables.size()};
+                d->all_tables.insert(d->all_tables.end(), f.tables.begin(), f.tables.end());
+                d->chk_prog_cf[s][i] = std::move(f);
+            }
+        }
     }
     if (d->min_lut) { int rc = build_plan(d, d->cclass, nullptr, nullptr, nullptr, d->cn_minsum_plan); if (rc) return rc; }
     return LUTLDPC_OK;
@@ -1363,7 +1378,12 @@ ResidentSpec resident_spec(const lutldpc_decoder *d, int S, int NT) {
         };
         fill(d->var_plan[s], d->var_prog_c[s], d->var_tab_c[s], R.var_prog[s], R.var_tab[s]);
         fill(d->dec_plan[s], d->dec_prog_c[s], d->dec_tab_c[s], R.dec_prog[s], R.dec_tab[s]);
-        if (!d->min_lut) fill(d->chk_plan[s], d->chk_prog_c[s], d->chk_tab_c[s], R.chk_prog[s], R.chk_tab[s]);
+        if (!d->min_lut && d->chk_plan[s].valid)
+            for (size_t c = 0; c < d->chk_prog_c[s].size(); c++) {      // over full labels where that form exists (one instruction per look-up)
+                const bool full = c < d->chk_tab_cf[s].size() && d->chk_tab_cf[s][c].second > 0;
+                R.chk_prog[s].push_back(full ? &d->chk_prog_cf[s][c] : &d->chk_prog_c[s][c]);
+                R.chk_tab[s].push_back(full ? d->chk_tab_cf[s][c] : d->chk_tab_c[s][c]);
+            }
     }
     return R;
 }

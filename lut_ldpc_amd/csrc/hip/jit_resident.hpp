@@ -128,8 +128,25 @@ inline bool emit_chk_frames(std::ostringstream &o, const Program &prog, int deg,
     o << ind << "        par_w = lshl_or(par, fs, par_w);\n" << ind << "    }\n";
     for (size_t j = 0; j < prog.ops.size(); j++) {
         const Op &op = prog.ops[j];
-        if (op.kind != 1) { err = "variable-type look-up in a check program"; return false; }
+        if (op.kind != 1 && op.kind != 2) { err = "variable-type look-up in a check program"; return false; }
         if ((size_t)op.dst >= name.size()) { name.resize((size_t)op.dst + 1); sm_of.resize(name.size(), 0); smname.resize(name.size()); }
+        if (op.kind == 2) {       // table over the children's full labels (lut_program.hpp: chk_full_label_program)
+            bool p2 = true;
+            for (int c = 0; c < op.nchild; c++) p2 = p2 && jit_pow2(op.mult[c]) && jit_pow2(op.childK[c]);
+            std::string label;
+            for (int c = 0; c < op.nchild; c++) {
+                const std::string &xn = name[(size_t)op.child[c]];
+                if (xn.empty()) { err = "operand read before it is written"; return false; }
+                if (c == 0) label = op.mult[c] == 1 ? xn : "(" + xn + " * " + S_(op.mult[c]) + "u)";
+                else if (p2) label = "lshl_or(" + xn + ", " + S_(__builtin_ctz(op.mult[c])) + ", " + label + ")";
+                else label = "(" + label + " + " + xn + " * " + S_(op.mult[c]) + "u)";
+            }
+            const std::string t = "t" + S_((long long)j);
+            o << ind << "    const uint32_t " << t << " = tc[" << op.tab_off << "u + " << label << "];\n";
+            name[(size_t)op.dst] = t;
+            if (op.out_idx >= 0) o << ind << "    out[" << op.out_idx << "] = lshl_or(" << t << ", fs, out[" << op.out_idx << "]);\n";
+            continue;
+        }
         bool all_pow2 = jit_pow2(op.half_len);
         for (int c = 0; c < op.nchild; c++) all_pow2 = all_pow2 && jit_pow2(op.mult[c]) && jit_pow2((uint32_t)op.childK[c] >> 1);
         std::string label, par;

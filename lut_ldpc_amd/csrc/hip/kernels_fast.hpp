@@ -44,7 +44,9 @@ namespace lutldpc {
 // (src/LDPC_Code_LUT.cpp:284-289), so the inputs are read from the N initial-message rows through a second table holding the
 // NODE of every check edge -- the E edge rows are written for the first time by this pass, no separate copy kernel.
 constexpr int kCnAllButOneMaxDeg = 16;     // checks up to this degree: all-but-one minima from prefix / suffix minima (registers: DEG - 2 suffixes)
-template <int DEG, int UNR, int PACK, bool CHAIN, typename PT, bool FIRST = false>
+// (ABO: the largest degree that takes the all-but-one form in this instantiation -- the fused kernels of the lean degree buckets keep
+// their few wide checks on the running-minima form, whose registers do not grow with the degree)
+template <int DEG, int UNR, int PACK, bool CHAIN, typename PT, bool FIRST = false, int ABO = kCnAllButOneMaxDeg>
 __device__ __forceinline__ void cn_minsum_body(
     const PT &P, int block, uint8_t *msgs, const uint32_t *__restrict__ state_w, uint32_t *__restrict__ vfail_w,
     const int32_t *__restrict__ fast_idx, const ChainParams CH = ChainParams{}, uint8_t *lds_tab = nullptr,
@@ -141,8 +143,8 @@ __device__ __forceinline__ void cn_minsum_body(
             if (i + u >= last) break;
             uint32_t r[DEG];
             uint32_t tn;
-            if constexpr (DEG <= kCnAllButOneMaxDeg) {
-            // The extrinsic magnitude of an edge, `mag == min1 ? min2 : min1` (src/LDPC_Code_LUT.cpp:376-396), IS the minimum over the
+            if constexpr (DEG <= ABO) {
+            // The extrinsic magnitude of an edge, `mag == min1 ? min2 : min1` (src/LDPC_Code_LUT.cpp:367-390), IS the minimum over the
             // OTHER edges of the check.  All DEG of them come out of suffix minima, a running prefix minimum and one combination
             // per inner edge -- 3 (DEG - 2) two-input minima, the least any scheme needs -- instead of two compare-selects per edge on
             // the way in plus an equality test and a select per edge on the way out: 135 instead of 215 vector instructions for a
@@ -607,6 +609,9 @@ constexpr int kFusedMaxTables = 20;
 constexpr int kFusedBuckets = 4;
 constexpr int kFusedVnDeg[kFusedBuckets] = {8, 12, 20, 8};
 constexpr int kFusedCnDeg[kFusedBuckets] = {8, 16, 32, 10};
+// checks up to this degree use the all-but-one minima inside the fused kernel of a bucket (cn_minsum_body: ABO): the suffix array of a
+// degree-16 check costs bucket 1 two waves per SIMD (79 -> 104 registers), of a degree-10 check bucket 3 one (63 -> 72)
+constexpr int kFusedAboDeg[kFusedBuckets] = {8, 10, 16, 8};
 // the bucket a code runs in: the leanest one that holds its degrees -- bucket 3 (variable degrees <= 8, check degrees <= 10, 8 waves
 // per SIMD like bucket 0 but with SGPR spills in the widest check bodies) sits between buckets 0 and 1: the irregular N = 64800
 // code of the reference has five checks of degree 9 among 32400 (+4.5 % over bucket 1, which runs 5 waves per SIMD)
@@ -637,11 +642,11 @@ struct FusedParams {
     RoleParams role[kFusedMaxRoles];
 };
 
-template <int PACK, bool CHAIN, bool FIRST, int... Ds>
+template <int PACK, bool CHAIN, bool FIRST, int ABO, int... Ds>
 __device__ __forceinline__ void fused_cn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *msgs, const uint32_t *state_w,
                                                 uint32_t *vfail_w, const int32_t *fast_idx, uint8_t *lds_tab, const uint8_t *cha, const uint8_t *tables, uint8_t *hard,
                                                 const uint8_t *msg0) {
-    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN, RoleParams, FIRST>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables, hard, msg0), 0) : 0), ...);
+    ((P.deg == Ds + 2 ? (cn_minsum_body<Ds + 2, 1, PACK, CHAIN, RoleParams, FIRST, ABO>(P, block, msgs, state_w, vfail_w, fast_idx, P.chain, lds_tab, cha, tables, hard, msg0), 0) : 0), ...);
 }
 template <int PACK, bool CHECK, int... Ds>
 __device__ __forceinline__ void fused_vn_switch(const RoleParams &P, int block, std::integer_sequence<int, Ds...>, uint8_t *lds_tab, uint8_t *msgs,
@@ -671,11 +676,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BUCKET == 
         // chain fusion (dual-diagonal codes: DVB-S2 at every rate, IRA): every bucket has the chained check bodies
         constexpr auto degs = std::make_integer_sequence<int, MAXCN - 1>{};
         if (!P.first) {
-            if (P.chain.on || P.chain.hard) fused_cn_switch<PACK, true, false>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
-            else fused_cn_switch<PACK, false, false>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            if (P.chain.on || P.chain.hard) fused_cn_switch<PACK, true, false, kFusedAboDeg[BUCKET]>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            else fused_cn_switch<PACK, false, false, kFusedAboDeg[BUCKET]>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
         } else {                           // iteration 0 (two launches per decode): inputs from the initial-message rows
-            if (P.chain.on) fused_cn_switch<PACK, true, true>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
-            else fused_cn_switch<PACK, false, true>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            if (P.chain.on) fused_cn_switch<PACK, true, true, kFusedAboDeg[BUCKET]>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
+            else fused_cn_switch<PACK, false, true, kFusedAboDeg[BUCKET]>(P, rb, degs, msgs, state_w, vfail_w, fast_idx, lds_tab, cha, tables, hard, msg0);
         }
     }
     else fused_vn_switch<PACK, CHECK>(P, rb, std::make_integer_sequence<int, MAXVN>{}, lds_tab, msgs, cha, hard, state_w, vfail_w, tables, fast_idx);
