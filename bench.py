@@ -514,12 +514,16 @@ def main():
     del src_buf, dst_buf
     # HBM bytes per pass from the PMC counters (collected in separate rocprofv3 --pmc passes and
     # committed under profiles/; valid only for the workload/batch/mode they were taken on)
-    # (a counter set counts only when it was taken on THIS build of the library -- the build stamp of describe() -- otherwise null)
-    build_stamp = dec.describe().get("build")
+    # (a counter set counts only when it was taken on THIS device code -- describe()'s hash of the kernel sources, or the compile-time
+    # stamp for sets that predate the hash -- otherwise null)
+    build_stamp, src_hash = dec.describe().get("build"), dec.describe().get("kernel_sources")
+
+    def same_code(t):
+        return (src_hash is not None and t.get("kernel_sources") == src_hash) or t.get("build") == build_stamp
     traffic = None
     for f in sorted((ROOT / "profiles").glob("*pmc_traffic*.json"), reverse=True):
         t = json.loads(f.read_text())
-        if t.get("build") == build_stamp and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
+        if same_code(t) and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode and t.get("message_bytes", 1) == b_msg:
             traffic = t.get("fused_pass_hbm_bytes_per_launch" if fu["launches"] else "resident_hbm_bytes_per_launch" if prof.get("resident", {}).get("launches") else "vn_pass_hbm_bytes_per_pass")
             break
     # what limits the dominant kernel on the chip besides HBM (SQ counters collected by tools/profile_round.sh in their own
@@ -527,12 +531,11 @@ def main():
     limiter = None
     for f in sorted((ROOT / "profiles").glob("*pmc_limiter*.json"), reverse=True):
         t = json.loads(f.read_text())
-        if t.get("build") == build_stamp and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode:
+        if same_code(t) and t.get("workload") == args.workload and t.get("batch") == B and t.get("mode") == args.mode:
             limiter = {"valu_busy": t["valu_busy"], "lds_busy": t["lds_busy"],
                        "lds_bank_conflict_share_of_lds_cycles": t["lds_bank_conflict_share_of_lds_cycles"],
                        "hbm_share_of_achievable_6p3TBps": None, "source": f.name,
-                       "note": "shares of the launch during which the vector ALUs issue / the LDS is busy (rocprofv3 --pmc); "
-                               "the kernel is co-limited: no single unit is saturated, all three are above 70 %"}
+                       "note": "shares of the launch during which the vector ALUs issue / the LDS is busy (rocprofv3 --pmc)"}
             break
     if fu["launches"]:
         # skewed two-half pipeline: one decode = 2*I launches of pass_fused_kernel which together carry the

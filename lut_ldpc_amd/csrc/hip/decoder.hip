@@ -1695,7 +1695,9 @@ int sample_tiles(lutldpc_decoder *d, const ChannelCells &C, uint64_t seed, uint3
 
 void make_describe(lutldpc_decoder *d) {
     std::ostringstream o;
-    o << "{\"build\":\"" << __DATE__ << " " << __TIME__ << "\",\"tile_frames\":" << d->tile() << ",\"message_bytes\":" << (d->pack == 2 ? "0.5" : "1") << ",\"pack\":" << d->pack << ",\"vector_bytes_per_lane\":4"
+    o << "{\"build\":\"" << __DATE__ << " " << __TIME__ << "\",\"kernel_sources\":\"" <<
+#include "kernel_src_hash.inc"
+      << "\",\"tile_frames\":" << d->tile() << ",\"message_bytes\":" << (d->pack == 2 ? "0.5" : "1") << ",\"pack\":" << d->pack << ",\"vector_bytes_per_lane\":4"
       << ",\"nodes_per_block\":" << d->nodes_per_block << ",\"vn_edges_per_wave\":" << d->vn_edges_per_wave << ",\"cn_edges_per_wave\":" << d->cn_edges_per_wave << ",\"use_fast\":" << d->use_fast
       << ",\"vn_classes\":[";
     for (size_t i = 0; i < d->vclass.size(); i++) {

@@ -36,6 +36,6 @@ bench = src / "bench.json"
 if bench.exists():
     b = json.loads(bench.read_text().strip().splitlines()[-1])
     res.update({"workload": (sys.argv[4] if len(sys.argv) > 4 else "dvbs2"), "batch": b["config"]["frames_per_gpu_per_step"], "mode": "fixed",
-                "build": b["config"]["kernels"].get("build")})
+                "build": b["config"]["kernels"].get("build"), "kernel_sources": b["config"]["kernels"].get("kernel_sources")})
 out.write_text(json.dumps(res, indent=1))
 print(json.dumps({k: v for k, v in res.items() if k != "counters_per_launch"}, indent=1))

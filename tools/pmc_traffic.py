@@ -38,7 +38,7 @@ res = {
     "algorithmic": {"fused_pass_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]},
     "resident_hbm_bytes_per_launch": sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in resident) if resident else None,
     "workload": (sys.argv[3] if len(sys.argv) > 3 else "dvbs2"), "batch": bench["config"]["frames_per_gpu_per_step"], "mode": "fixed",
-    "build": bench["config"]["kernels"].get("build"),
+    "build": bench["config"]["kernels"].get("build"), "kernel_sources": bench["config"]["kernels"].get("kernel_sources"),
     "message_bytes": bench["config"]["kernels"]["message_bytes"],
 }
 out.write_text(json.dumps(res, indent=1))

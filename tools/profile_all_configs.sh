@@ -7,6 +7,7 @@ set -e
 OUT=$1; shift
 WLS=${@:-"dvbs2 c2 c5 c5chk c1 twin"}
 R=$GRAFT_REPO_ROOT
+mkdir -p "$R/$OUT"
 for wl in $WLS; do
     args="--workload $wl"
     [ "$wl" = "c2" ] && args="$args --batch 4096"
