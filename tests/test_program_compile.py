@@ -206,3 +206,16 @@ def test_resident_refuses_codes_that_do_not_fit_the_lds():
     with pytest.raises(L.LutLdpcError):
         dec.resident_source(4)
     dec.close()
+
+
+def test_describe_names_the_device_code_by_a_hash_of_its_sources():
+    """bench.py replays a counter set from profiles/ only when it was taken on the running device code: describe() carries a hash of
+    everything under csrc/hip/ (Makefile: kernel_src_hash.inc), stable across rebuilds of unchanged sources."""
+    import hashlib
+    from pathlib import Path
+    dec = product_decoder(oracle_codec("n500_q4_i8"), device=-1)
+    h = dec.describe()["kernel_sources"]
+    hip = Path(__file__).resolve().parent.parent / "lut_ldpc_amd" / "csrc" / "hip"
+    files = sorted([*hip.glob("*.hpp"), *hip.glob("*.hip")], key=lambda p: "hip/" + p.name)
+    assert h == hashlib.sha256(b"".join(p.read_bytes() for p in files)).hexdigest()[:16]
+    dec.close()
