@@ -212,6 +212,13 @@ struct lutldpc_decoder {
     int npw_vn(int deg) const { return nodes_per_wave > 0 ? nodes_per_wave : std::max(1, (vn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
     int npw_cn(int deg) const { return nodes_per_wave_cn > 0 ? nodes_per_wave_cn : std::max(1, (cn_edges_per_wave >> work_shift) / std::max(deg, 1)); }
     int npw_cn_class(size_t ci) const { return ci < cn_npw_class.size() && cn_npw_class[ci] > 0 ? cn_npw_class[ci] : npw_cn(cclass[ci].deg); }
+    // Placement search (place_rows): where the row buffers of a large batch land in HBM decides 6 % of the decode rate (one
+    // process, fresh allocations of the same sizes: 241.8 ... 262.9 k codewords/s on DVB-S2, each level steady to 0.1 %;
+    // profiles/r03_level_probe_*.txt), and nothing visible from here predicts it -- so the first decode of a batch size tries
+    // up to `place_candidates` allocations, times three iterations of the fused pipeline on each and keeps the fastest (it stops early
+    // once a candidate stands clear of the slowest seen).  LUTLDPC_PLACE=0 off, =n at most n candidates.
+    int place_candidates = 16;
+    std::string place_info = "null";
     int use_fast = 1;
     int pack = 1;               // 2: nibble rows (all alphabets <= 16 labels), 1: byte rows
     int skew = 1;               // two-half skewed pipeline through pass_fused_kernel (one frame group: second half empty)
@@ -723,6 +730,8 @@ int upload_static(lutldpc_decoder *d) {
     return LUTLDPC_OK;
 }
 
+int place_rows(lutldpc_decoder *d, int Bpad);
+void make_describe(lutldpc_decoder *d);
 int ensure_batch(lutldpc_decoder *d, int B) {
     int Bpad = d->bpad(B);
     if (Bpad <= d->Bcap) return LUTLDPC_OK;
@@ -747,7 +756,9 @@ int ensure_batch(lutldpc_decoder *d, int B) {
     HIP_TRY(hipMemsetAsync(d->d_cha_t.p, 0, d->d_cha_t.bytes(), d->stream));
     HIP_TRY(hipMemsetAsync(d->d_msg0_t.p, 0, d->d_msg0_t.bytes(), d->stream));
     d->Bcap = Bpad;
-    return LUTLDPC_OK;
+    if (getenv("LUTLDPC_DEBUG_ADDR"))        // (tools/level_probe_realloc.py: where did the row buffers of this handle land?)
+        fprintf(stderr, "lutldpc rows: msgs %p cha %p msg0 %p hard %p (%zu MB of messages)\n", (void *)d->d_msgs.p, (void *)d->d_cha_t.p, (void *)d->d_msg0_t.p, (void *)d->d_hard.p, d->d_msgs.bytes() >> 20);
+    return place_rows(d, Bpad);
 }
 
 // Always on, O(1), before every decode: the batch buffers every kernel addresses rows in exist and hold Bpad frames.  (The one
@@ -1439,6 +1450,86 @@ bool resident_pick(const lutldpc_decoder *d, int G, int &S_out, int &NT_out, int
 
 bool resident_active(const lutldpc_decoder *d) { return d->resident_ok && d->use_resident; }
 
+// Placement search for the row buffers of a large batch (see lutldpc_decoder::place_candidates).  Candidate 0 is what ensure_batch
+// has just allocated; every further candidate is a fresh set of the same sizes, ALL kept alive until the choice is made (a freed
+// set would be handed out again).  The probe is the real thing on zeroed rows: frame states, then three iterations of the fused
+// pipeline (six launches), timed with events on the decoder's stream; the second run counts.  Only for the skewed streaming path
+// and batches whose rows exceed 1 GiB -- below that the launches are not bound by HBM.  Allocation failures end the search quietly.
+int place_rows(lutldpc_decoder *d, int Bpad) {
+    const int G = Bpad / d->tile();
+    const size_t total = d->d_msgs.bytes() + d->d_cha_t.bytes() + d->d_msg0_t.bytes() + d->d_hard.bytes();
+    d->place_info = "null";
+    if (d->place_candidates < 2 || d->device < 0 || !d->skew || !d->skew_ok || resident_active(d) || d->trace.level > 1 || total < ((size_t)1 << 30) || d->max_iters_created < 2) return LUTLDPC_OK;
+    struct RowSet { DevBuf<uint8_t> msgs, cha, msg0, hard; float ms = 0.f; int id = 0; void release() { msgs.release(); cha.release(); msg0.release(); hard.release(); } };
+    std::vector<std::unique_ptr<RowSet>> parked;      // the candidates tried so far, except the one the decoder holds right now
+    const size_t n_msgs = d->d_msgs.n, n_node = d->d_cha_t.n;
+    auto swap_in = [&](RowSet &r) { std::swap(d->d_msgs, r.msgs); std::swap(d->d_cha_t, r.cha); std::swap(d->d_msg0_t, r.msg0); std::swap(d->d_hard, r.hard); };
+    const int I0 = d->max_iters; const bool psc0 = d->psc, pisc0 = d->pisc; const int prof0 = d->profiling;
+    d->max_iters = std::min(3, d->max_iters_created); d->psc = d->pisc = false; d->profiling = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = LUTLDPC_OK;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
+    std::vector<float> times;                          // probe time of every candidate, in the order tried
+    size_t parked_bytes = 0, mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+    const size_t mem_budget = mem_free / 3;          // (a third: two lanes of a device may search at the same time)
+    float cur_ms = 0.f; int cur_id = 0;                // the candidate the decoder holds
+    for (int k = 0; k < d->place_candidates && rc == LUTLDPC_OK; k++) {
+        if (k > 0) {
+            std::unique_ptr<RowSet> r(new RowSet());
+            if (parked_bytes + 2 * total > mem_budget) break;      // keep the search within a third of what was free when it started
+            if (r->msgs.alloc(n_msgs) != hipSuccess || r->cha.alloc(n_node) != hipSuccess || r->msg0.alloc(n_node) != hipSuccess || r->hard.alloc(n_node) != hipSuccess ||
+                hipMemsetAsync(r->msgs.p, 0, r->msgs.bytes(), d->stream) != hipSuccess || hipMemsetAsync(r->cha.p, 0, r->cha.bytes(), d->stream) != hipSuccess ||
+                hipMemsetAsync(r->msg0.p, 0, r->msg0.bytes(), d->stream) != hipSuccess || hipMemsetAsync(r->hard.p, 0, r->hard.bytes(), d->stream) != hipSuccess) {
+                (void)hipGetLastError(); r->release(); break;        // out of memory: choose among what was tried
+            }
+            swap_in(*r);                               // the decoder works on candidate k, r holds candidate cur_id
+            r->ms = cur_ms; r->id = cur_id;
+            parked.push_back(std::move(r));
+            parked_bytes += total;
+            cur_id = k;
+        }
+        for (int rep = 0; rep < 2 && rc == LUTLDPC_OK; rep++) {
+            if ((rc = launch_state(d, Bpad, Bpad, 0, 0))) break;
+            if (hipEventRecord(e0, d->stream) != hipSuccess) { rc = -1; break; }
+            if ((rc = iterate_skewed(d, Bpad, Bpad, G))) break;
+            if (hipEventRecord(e1, d->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = -1; break; }
+            (void)hipEventElapsedTime(&cur_ms, e0, e1);
+        }
+        times.push_back(cur_ms);
+        // the levels are discrete (on DVB-S2: 5.97 / 6.25 / 6.45-6.6 ms for the probe, the top one in one allocation out of eight):
+        // stop as soon as one candidate stands 6.5 % clear of the slowest seen
+        if (times.size() >= 4) {
+            const float lo = *std::min_element(times.begin(), times.end()), hi = *std::max_element(times.begin(), times.end());
+            if (lo <= 0.935f * hi) break;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    d->max_iters = I0; d->psc = psc0; d->pisc = pisc0; d->profiling = prof0;
+    if (rc != LUTLDPC_OK) {        // a probe failed: keep what the decoder holds, report nothing (the decode that follows surfaces a real error)
+        (void)hipGetLastError();
+        for (auto &c : parked) c->release();
+        return LUTLDPC_OK;
+    }
+    for (auto &c : parked)
+        if (c->ms < cur_ms) { swap_in(*c); std::swap(c->ms, cur_ms); std::swap(c->id, cur_id); }      // the decoder ends up with the fastest set
+    std::ostringstream o;
+    o << "{\"candidates\":" << times.size() << ",\"chosen\":" << cur_id << ",\"probe_ms\":[";
+    for (size_t k = 0; k < times.size(); k++) o << (k ? "," : "") << times[k];
+    o << "]}";
+    d->place_info = o.str();
+    auto &cand = parked;
+    for (auto &c : cand) { c->msgs.release(); c->cha.release(); c->msg0.release(); c->hard.release(); }
+    // the probes ran on zeroed rows and left their messages behind: defined content again (see ensure_batch)
+    HIP_TRY(hipMemsetAsync(d->d_msgs.p, 0, d->d_msgs.bytes(), d->stream));
+    HIP_TRY(hipMemsetAsync(d->d_hard.p, 0, d->d_hard.bytes(), d->stream));
+    d->drop_graphs();
+    make_describe(d);
+    if (getenv("LUTLDPC_DEBUG_ADDR")) fprintf(stderr, "lutldpc placement: %s -> msgs %p\n", d->place_info.c_str(), (void *)d->d_msgs.p);
+    return LUTLDPC_OK;
+}
+
 int resident_plan_for(lutldpc_decoder *d, int G, lutldpc_decoder::ResidentPlan **out) {
     auto it = d->resident_plans.find(G);
     if (it == d->resident_plans.end()) {
@@ -1712,7 +1803,7 @@ void make_describe(lutldpc_decoder *d) {
           << (d->min_lut ? (f ? "cn_minsum_fast_kernel" : "cn_minsum_generic_kernel")
                          : (!d->chk_jit.empty() && i < d->chk_jit[0].size() && d->chk_jit[0][i]) ? "lutldpc_jit_pass" : "tree_pass_kernel<CHK>") << "\"}";
     }
-    o << "],\"resident\":" << (resident_active(d) ? 1 : 0) << ",\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"compaction_min_groups\":" << [&] { for (int G = 1; G <= 2 * kPermuteMaxGroups; G++) if (compaction_on(d, G)) return G; return -1; }() << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << "}";
+    o << "],\"resident\":" << (resident_active(d) ? 1 : 0) << ",\"skewed_pipeline\":" << ((d->skew && d->skew_ok) ? 1 : 0) << ",\"fused_bucket\":" << d->fused_bucket_id << ",\"compaction\":" << (d->use_compact < 0 ? 2 : d->use_compact) << ",\"compaction_min_groups\":" << [&] { for (int G = 1; G <= 2 * kPermuteMaxGroups; G++) if (compaction_on(d, G)) return G; return -1; }() << ",\"chain_nodes\":" << (d->use_chain ? d->n_chain_nodes : 0) << ",\"placement\":" << d->place_info << "}";
     d->describe = o.str();
 }
 
@@ -1807,6 +1898,7 @@ int lutldpc_decoder_create(int nvar, int nchk, const int32_t *dv, const int32_t 
     if (const char *e = getenv("LUTLDPC_RESIDENT_U")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) d->resident_U = v; }
     if (const char *e = getenv("LUTLDPC_CHAIN")) d->use_chain = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_CHK_FULL")) d->chk_full_labels = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LUTLDPC_PLACE")) { int v = atoi(e); if (v >= 0 && v <= 32) d->place_candidates = v; }
     if (const char *e = getenv("LUTLDPC_COMPACT")) d->use_compact = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_KEEP")) d->compact_keep = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LUTLDPC_COMPACT_FIRST")) { int v = atoi(e); if (v >= 1) d->compact_first = v; }

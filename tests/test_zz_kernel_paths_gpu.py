@@ -147,3 +147,33 @@ def test_compaction_that_drops_the_rows_of_finished_frames(monkeypatch):
     it = _compare(cd, dec, cha, msg, True, True, flat=True)
     assert len(set(it.tolist())) > 8 and (it == 0).sum() == 1
     dec.close()
+
+
+def test_placement_search_of_the_row_buffers_changes_nothing_but_where_they_are(monkeypatch):
+    """A batch whose rows exceed 1 GiB makes the streaming decoder try several allocations of its row buffers and keep the fastest
+    (decoder.hip: place_rows; DESIGN.md "The levels are buffer placement"): describe() reports the search, the outputs equal those of a
+    decoder that takes the first allocation (LUTLDPC_PLACE=0) in both exit modes, and a sample of frames equals the oracle."""
+    cd = oracle_codec("dvbs2_q4_i6")
+    B = 5300                                   # 11 frame groups: 1.19 GB of rows
+    cha, msg, _ = awgn_labels(cd, B, 1.4, seed=77)
+    cha[:3] = cd.nq_cha - 1; msg[:3] = int(cd.nq_msg[0]) - 1         # a few noise-free frames (they pass the test on the channel decisions)
+    out = {}
+    for place in ("16", "0"):
+        monkeypatch.setenv("LUTLDPC_PLACE", place)
+        dec = product_decoder(cd)
+        for psc in (False, True):
+            dec.set_exit_conditions(cd.max_iters, psc, psc)
+            out[place, psc] = dec.lut_decode_batch(cha, msg)
+        info = dec.describe()["placement"]
+        if place == "0":
+            assert info is None
+        else:
+            assert info["candidates"] >= 2 and len(info["probe_ms"]) == info["candidates"] and 0 <= info["chosen"] < info["candidates"], info
+            assert min(info["probe_ms"]) == pytest.approx(info["probe_ms"][info["chosen"]])
+        dec.close()
+    for psc in (False, True):
+        assert (out["16", psc][0] == out["0", psc][0]).all() and (out["16", psc][1] == out["0", psc][1]).all()
+        cd.set_exit_conditions(cd.max_iters, psc, psc)
+        idx = np.r_[0:4, B - 24:B]
+        wb, wi = cd.lut_decode_batch(cha[idx], msg[idx])
+        assert (wb == out["16", psc][0][idx]).all() and (wi == out["16", psc][1][idx]).all()
