@@ -16,7 +16,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/trace" -- pytho
 find "$R/$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$R/$OUT/kernel_stats.csv" \;
 pmc() {   # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$OUT/pmc_$name" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs --frame-loop-steps 0 --as-shipped-steps 0 --no-kernel-events --reps 0 $BENCH_ARGS > /dev/null 2> "$R/$OUT/pmc_$name.err"
+    # (LUTLDPC_PLACE=0: the counter means are per launch of the decode proper -- the placement search of a large batch would add its
+    # probe launches, zeroed rows and three iterations each, to the same kernel name; bytes and instructions per launch do not depend
+    # on where the rows landed)
+    LUTLDPC_PLACE=0 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$OUT/pmc_$name" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs --frame-loop-steps 0 --as-shipped-steps 0 --no-kernel-events --reps 0 $BENCH_ARGS > /dev/null 2> "$R/$OUT/pmc_$name.err"
     find "$R/$OUT/pmc_$name" -name "*counter_collection.csv" -exec cp {} "$R/$OUT/pmc_$name.csv" \;
     rm -rf "$R/$OUT/pmc_$name"
 }
