@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <filesystem>
+#include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
@@ -486,7 +487,7 @@ void LDPC_BER_Sim_BP::sim_batch(double snr, int snr_index, int64_t frame0, int B
 
 // ------------------------------------------------------------------ ber_sim main
 int ber_sim_main(int argc, char **argv) {
-    int seed = 0, device = 0, lanes = 2;
+    int seed = 0, device = 0, lanes = 0;
     std::vector<int> devices;
     std::string exchange = "auto";
     std::string base_dir = fs::current_path().string(), custom_name, params;
@@ -500,8 +501,9 @@ int ber_sim_main(int argc, char **argv) {
                      "  -s [ --seed ] arg (=0)    random seed\n"
                      "  -d [ --device ] arg (=0)  HIP device ordinal, a list 0,1,2,3 or `all`: the frames of every SNR point are sharded\n"
                      "                            over the devices, counters over RCCL (build-side option)\n"
-                     "  --lanes arg (=2)          host threads (simulation objects, streams) per device: batches of one overlap the\n"
-                     "                            sampler / transfers of the other; 1 = the plain synchronous loop\n"
+                     "  --lanes arg (=0)          host threads (simulation objects, streams) per device: batches of one overlap the\n"
+                     "                            sampler / transfers of the other; 1 = the plain synchronous loop; 0 = two, or one\n"
+                     "                            where a single batch occupies the whole device (N x batch_frames >= 2^30)\n"
                      "  --exchange arg (=auto)    rccl | host | auto: how the counters of the ranks are combined\n";
     };
     try {
@@ -550,6 +552,17 @@ int ber_sim_main(int argc, char **argv) {
         const std::string codec_type = ini.get("Sim.codec_type", "none");
         if (devices.empty()) devices.push_back(device);
         if (const char *e = std::getenv("LUTLDPC_LANES")) lanes = std::atoi(e);
+        if (lanes == 0) {
+            // auto: two lanes hide the sampler, the transfers and the host prefix of one batch behind the decode of the other -- worth
+            // 30 % on the short codes; a batch of a long code (DVB-S2 at 32768 frames: 6.8 GB of rows, 120 ms of HBM-bound launches)
+            // leaves nothing to overlap with, and the second lane's set-up (its own decoder, generated kernels, placement search)
+            // costs a 1e6-frame point 5 % (profiles/r03_config4_one_gpu_ber_sim.txt: 4.11 s against 4.31 s)
+            lanes = 2;
+            const std::string codes_dir = ini.get("Sim.codes_dir", "codes"), parity = ini.get("LDPC.parity_filename", "");
+            std::ifstream al(fs::path(join(base_dir, codes_dir)) / (parity + ".alist"));
+            long long n_var = 0;
+            if (al && (al >> n_var) && n_var > 0 && n_var * (long long)ini.get("Sim.batch_frames", 32768) >= (1ll << 30)) lanes = 1;
+        }
         const bool is_bp = !(ini.has_section("LUT") || codec_type == "LUT");
         if (is_bp && devices.size() == 1) lanes = 1;               // (the [BP] comparison decoder draws its noise on all host cores already)
         // output_verbosity > 0 prints every frame's stimuli / message dumps to std::cout in frame order (src/LDPC_Code_LUT.cpp:228-238,
