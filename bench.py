@@ -381,7 +381,9 @@ def main():
         local %= torch.cuda.device_count()        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # BENCH_DIST_FORCE=1: a process group for ONE rank too (under torch.distributed.run --nproc-per-node 1) -- the rehearsal of the RCCL
+    # calls of the N > 1 path (init with device_id, barrier, int64 / float64 all-reduce) on a one-GPU box
+    if world > 1 or os.environ.get("BENCH_DIST_FORCE"):
         import torch.distributed as dist
         if args.dist_backend == "nccl":           # RCCL over xGMI, one GPU per rank
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -580,7 +582,7 @@ def main():
         "config": {"workload": f"{alist}, {qc}-bit channel / {qm}-bit messages, {max_iter} iterations, min-LUT, "
                                f"{'fixed work (parity_check_iter=false)' if not psc else 'as shipped (syndrome checks, early termination)'}",
                    "frames_per_gpu_per_step": B, "N": N, "E": E, "design_sigma": sigma, "EbN0_dB": round(float(snr), 3),
-                   "mean_iterations_executed": it_exec, "parallelism": f"frames sharded over {world} GPU(s), counters all-reduced",
+                   "mean_iterations_executed": it_exec, "parallelism": f"frames sharded over {world} GPU(s), counters all-reduced" + (f" ({dist.get_backend()} process group)" if dist is not None else ""),
                    "kernels": dec.describe()},
         "roofline": roof,
         "roofline_cn_pass": None if not cn["launches"] else {

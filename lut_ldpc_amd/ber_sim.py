@@ -210,7 +210,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     comm = Comm()
-    if world > 1:
+    # LUTLDPC_DIST_FORCE=1: a process group even for ONE rank -- on a one-GPU box this is the only way to send the counter exchange
+    # through RCCL proper (all_gather / all_reduce of int64 on the device)
+    grouped = world > 1 or bool(os.environ.get("LUTLDPC_DIST_FORCE"))
+    if grouped:
         import torch
         import torch.distributed as dist
         use_gpu = torch.cuda.is_available()
@@ -224,7 +227,7 @@ def main(argv=None):
         dist.init_process_group(backend)
         comm = Comm(dist, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
     run(params, args.basedir, args.seed, args.custom_name, comm, device=local)
-    if world > 1:
+    if grouped:
         comm.dist.destroy_process_group()
     return 0
 

@@ -220,3 +220,37 @@ def test_cpp_multi_rank_ber_sim_equals_the_single_rank_result_file(tmp_path):
     for tag in ("_lanes", "_three"):
         for k in ("sim_SNRdB", "sim_Nframes", "sim_Ndatabits", "sim_frame_errors", "sim_data_bit_errors", "sim_uncoded_bit_errors"):
             assert (np.asarray(files[tag][k]) == np.asarray(a[k])).all(), (tag, k, files[tag][k], a[k])
+
+
+def test_counter_exchange_through_rccl_proper_with_one_rank(tmp_path):
+    """RCCL itself on the one GPU of the box (it refuses two ranks on a card, so ONE rank): the C++ ber_sim with `--exchange rccl`
+    (dlopen of librccl, ncclCommInitAll, ncclAllGather / ncclAllReduce of int64 on the device's stream) and the Python driver under
+    torch.distributed.run with a one-rank nccl process group (LUTLDPC_DIST_FORCE=1) write the same result file as the plain loop."""
+    base = _setup_basedir(tmp_path)
+    ini = (ROOT / "data" / "params" / "ber.ini.irregular.example").read_text().replace("Nframes  = 1e2", "Nframes  = 5000\n   batch_frames = 1024")
+    params = tmp_path / "ber_rccl.ini"
+    params.write_text(ini)
+    exe = ROOT / "lut_ldpc_amd" / "lib" / "ber_sim"
+    keys = ("sim_SNRdB", "sim_Nframes", "sim_Ndatabits", "sim_frame_errors", "sim_data_bit_errors", "sim_uncoded_bit_errors")
+    files = {}
+    for tag, extra in (("_plain", ["-d", "0", "--lanes", "1"]), ("_rccl", ["-d", "0", "--lanes", "2", "--exchange", "rccl"])):
+        r = subprocess.run([str(exe), "-p", str(params), "-b", str(base), "-s", "6", "-c", tag] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        if tag == "_rccl":
+            assert "1 device(s) x 2 lane(s), counters over RCCL" in r.stdout, r.stdout[-500:]
+        out = sorted((base / "results").glob(f"*{tag}/*_rseed0006.it"))
+        assert len(out) == 1
+        files[tag] = itload(out[0])
+    env = dict(os.environ, PYTHONPATH=str(ROOT), LUTLDPC_DIST_FORCE="1")
+    env.pop("LUTLDPC_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", "-m", "lut_ldpc_amd.ber_sim", "-p", str(params), "-b", str(base), "-s", "6", "-c", "_pyrccl"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = sorted((base / "results").glob("*_pyrccl/*_rseed0006.it"))
+    assert len(out) == 1
+    files["_pyrccl"] = itload(out[0])
+    assert files["_plain"]["sim_Nframes"].max() == 5000
+    for tag in ("_rccl", "_pyrccl"):
+        for k in keys:
+            assert (np.asarray(files[tag][k]) == np.asarray(files["_plain"][k])).all(), (tag, k)
