@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fill the design cache (data/design_cache/, LUTLDPC_DESIGN_CACHE) with the LUT designs of bench.py's workloads: host
 code only, no GPU.  The files travel to the GPU box with the tree, so a bench / profile run there starts in seconds
-instead of re-running the 50-iteration density evolution (~25 s for DVB-S2).  Usage: tools/warm_design_cache.py [workload...]"""
+instead of re-running the 50-iteration density evolution and the GF(2) rank of the parity-check matrix (about a second per workload on this host).  Usage: tools/warm_design_cache.py [workload...]"""
 import os
 import sys
 import time
