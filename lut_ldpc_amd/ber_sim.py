@@ -157,12 +157,32 @@ class BerSim:
         return buf.value.decode()
 
 
+def _placement_policy(params, world: int):
+    """The same rule as the C++ driver (ber_sim_driver.cpp, ber_sim_main): the placement search of the row buffers (0.1-0.4 s per
+    batch size for +2-6 % of the streaming kernels' rate) is left to runs in which a rank sees at least 64 full batches of an
+    SNR point; LUTLDPC_PLACE set by the user wins (the library reads it when the decoder is created)."""
+    import re
+    try:
+        txt = open(params).read()
+    except OSError:
+        return
+    def key(name, default):
+        m = re.search(r"^[ \t]*" + name + r"[ \t]*=[ \t]*([-+0-9.eE]+)", txt, re.M)
+        try:
+            return float(m.group(1)) if m else default
+        except ValueError:
+            return default
+    if key("Nframes", 1e2) / (max(world, 1) * max(1.0, key("batch_frames", 32768.0))) < 64.0:
+        os.environ.setdefault("LUTLDPC_PLACE", "0")
+
+
 def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False, batch_override=None):
     """LDPC_BER_Sim::run (src/LDPC_BER_Sim.cpp:121-155) + save(), sharded over comm.
 
     batch_override(sim, snr_index, frame0, B) -> [B, 4] replaces the device batch (sampler + decode + counting); the CPU
     tests of the multi-rank path pass the oracle there, with the simulation object created host-only (device = -1)."""
     comm = comm or Comm()
+    _placement_policy(params, comm.world)
     sim = BerSim(params, base_dir, seed, custom_name, -1 if batch_override else device)
     batch = (lambda i, f, b: batch_override(sim, i, f, b)) if batch_override else sim.batch
     t0 = time.perf_counter()

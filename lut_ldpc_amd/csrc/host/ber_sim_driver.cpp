@@ -568,6 +568,14 @@ int ber_sim_main(int argc, char **argv) {
         // output_verbosity > 0 prints every frame's stimuli / message dumps to std::cout in frame order (src/LDPC_Code_LUT.cpp:228-238,
         // 292-337): that text is only meaningful from ONE thread
         if (ini.get("LUT.output_verbosity", 0) > 0) { lanes = 1; if (devices.size() > 1) devices.resize(1); }
+        // The placement search of the row buffers (decoder.hip: place_rows, 0.1-0.4 s per batch size for +2-6 % of the streaming
+        // kernels' rate) pays for itself after some eight seconds of decoding at that size: a rank that sees fewer than 64
+        // full batches of its largest SNR point runs without (config 4 on eight GPUs: four batches per rank).  LUTLDPC_PLACE
+        // set by the user wins; the variable is read when a decoder is created.
+        {
+            const double per_rank = ini.get("Sim.Nframes", 1e2) / ((double)devices.size() * (double)std::max(lanes, 1) * (double)std::max(1, ini.get("Sim.batch_frames", 32768)));
+            if (per_rank < 64.0) setenv("LUTLDPC_PLACE", "0", 0);
+        }
         if (devices.size() > 1 || lanes > 1)
             return ber_sim_run_multi(params_path, base_dir, seed, custom_name, devices, lanes, exchange, false);
         std::unique_ptr<LDPC_BER_Sim> sim;
