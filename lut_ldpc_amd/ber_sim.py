@@ -165,24 +165,25 @@ def _placement_policy(params, world: int):
     try:
         txt = open(params).read()
     except OSError:
-        return
+        return False
     def key(name, default):
         m = re.search(r"^[ \t]*" + name + r"[ \t]*=[ \t]*([-+0-9.eE]+)", txt, re.M)
         try:
             return float(m.group(1)) if m else default
         except ValueError:
             return default
-    if key("Nframes", 1e2) / (max(world, 1) * max(1.0, key("batch_frames", 32768.0))) < 64.0:
-        os.environ.setdefault("LUTLDPC_PLACE", "0")
+    if "LUTLDPC_PLACE" not in os.environ and key("Nframes", 1e2) / (max(world, 1) * max(1.0, key("batch_frames", 32768.0))) < 64.0:
+        os.environ["LUTLDPC_PLACE"] = "0"
+        return True
+    return False
 
 
-def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False, batch_override=None):
+def _run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False, batch_override=None):
     """LDPC_BER_Sim::run (src/LDPC_BER_Sim.cpp:121-155) + save(), sharded over comm.
 
     batch_override(sim, snr_index, frame0, B) -> [B, 4] replaces the device batch (sampler + decode + counting); the CPU
     tests of the multi-rank path pass the oracle there, with the simulation object created host-only (device = -1)."""
     comm = comm or Comm()
-    _placement_policy(params, comm.world)
     sim = BerSim(params, base_dir, seed, custom_name, -1 if batch_override else device)
     batch = (lambda i, f, b: batch_override(sim, i, f, b)) if batch_override else sim.batch
     t0 = time.perf_counter()
@@ -211,6 +212,18 @@ def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, d
             print(f"Done simulating. Runtime = {runtime:g} seconds", flush=True)
     sim.close()
     return points, path
+
+
+def run(params, base_dir, seed=0, custom_name="", comm: Optional[Comm] = None, device=0, save=True, quiet=False, batch_override=None):
+    """`_run` under the placement policy of this run (the decoder is created at the first batch, so the variable stays set for the
+    whole run and is removed afterwards: a caller's later decoders decide for themselves)."""
+    comm = comm or Comm()
+    policy_set = _placement_policy(params, comm.world)
+    try:
+        return _run(params, base_dir, seed, custom_name, comm, device, save, quiet, batch_override)
+    finally:
+        if policy_set:
+            os.environ.pop("LUTLDPC_PLACE", None)
 
 
 def main(argv=None):
